@@ -1,0 +1,299 @@
+// fft_core.h -- per-thread building blocks of the negacyclic f64 FFT used by the blind-rotate
+// kernel (K5 in DESIGN.md).  Everything here is a "thread program": it touches only the
+// thread's own registers plus an LDS array, so the same code runs on a gfx950 wave and, for
+// the index-math tests in tests/emul, on the host one thread at a time.
+//
+// Transform: a real polynomial of N coefficients in Z[X]/(X^N+1) is folded to M = N/2 complex
+// points z_n = (x_n + i x_{n+M}) * e^{i pi n / N} and sent through an M-point DIF FFT that is
+// kept IN PLACE in mixed radix: M = R_0 * R_1 * ... * R_{s-1}, digit i has weight
+// W_i = prod_{j>i} R_j, pass i replaces time digit n_i by frequency digit k_i at the same
+// position.  The spectrum therefore ends in digit-reversed order, which nobody ever undoes:
+// the bootstrapping key is stored in the same order and the inverse transform (DIT, passes in
+// reverse) consumes it and returns natural order.
+//
+// Thread layout: T = M / P threads per polynomial, P points per thread (P = 8 or 16).
+//   R_i = P for every pass but possibly the last, R_last = M / P^(s-1) (divides P).
+//   pass i, thread t: base = (t / W_i) * (W_i * R_i) + (t % W_i), points base + j * W_i.
+//   last pass with R_last < P: thread t owns P contiguous points = P / R_last small DFTs.
+// Between passes the points go through an LDS exchange buffer (one write + one read per
+// pass boundary); the first forward pass reads registers, the last leaves registers.
+#pragma once
+#include <stdint.h>
+#include <type_traits>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline __attribute__((always_inline))
+#endif
+
+namespace dctfhe {
+
+struct cplx { double re, im; };
+
+HD cplx cmk(double re, double im) { cplx c; c.re = re; c.im = im; return c; }
+HD cplx cadd(cplx a, cplx b) { return cmk(a.re + b.re, a.im + b.im); }
+HD cplx csub(cplx a, cplx b) { return cmk(a.re - b.re, a.im - b.im); }
+HD cplx cmul(cplx a, cplx b) {
+  return cmk(__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.re, b.im, a.im * b.re));
+}
+HD cplx cmulc(cplx a, cplx b) {  // a * conj(b)
+  return cmk(__builtin_fma(a.re, b.re, a.im * b.im), __builtin_fma(a.im, b.re, -(a.re * b.im)));
+}
+HD cplx csqr(cplx a) { return cmk(__builtin_fma(a.re, a.re, -(a.im * a.im)), 2.0 * a.re * a.im); }
+HD cplx cfma(cplx a, cplx b, cplx acc) {  // acc + a*b
+  cplx r;
+  r.re = __builtin_fma(a.re, b.re, acc.re); r.re = __builtin_fma(-a.im, b.im, r.re);
+  r.im = __builtin_fma(a.re, b.im, acc.im); r.im = __builtin_fma(a.im, b.re, r.im);
+  return r;
+}
+
+// compile-time loop
+template <int I, int E, class F>
+HD void static_for(F&& f) {
+  if constexpr (I < E) { f(std::integral_constant<int, I>{}); static_for<I + 1, E>(static_cast<F&&>(f)); }
+}
+
+// cos/sin(2 pi k / 64), k = 0..16 (first quadrant); everything up to radix 16 plus the
+// e^{i pi j/(2P)} twist constants comes out of this table by symmetry.
+HD double q64cos(int k) {
+  constexpr double t[17] = {1.0, 0.99518472667219688624, 0.98078528040323044913, 0.95694033573220886494,
+                            0.92387953251128675613, 0.88192126434835502971, 0.83146961230254523708,
+                            0.77301045336273696081, 0.70710678118654752440, 0.63439328416364549822,
+                            0.55557023301960222474, 0.47139673682599764856, 0.38268343236508977173,
+                            0.29028467725446236764, 0.19509032201612826785, 0.09801714032956060199, 0.0};
+  return t[k];
+}
+// e^{+2 pi i k / 64}
+HD cplx root64(int k) {
+  k &= 63;
+  const int q = k >> 4, r = k & 15;
+  const double c = q64cos(r), s = q64cos(16 - r);
+  switch (q) {
+    case 0: return cmk(c, s);
+    case 1: return cmk(-s, c);
+    case 2: return cmk(-c, -s);
+    default: return cmk(s, -c);
+  }
+}
+
+// multiply by the compile-time constant e^{SIGN * 2 pi i K / 64}
+template <int K, int SIGN>
+HD cplx mul_root64(cplx a) {
+  constexpr int k = ((SIGN > 0 ? K : -K) % 64 + 64) % 64;
+  if constexpr (k == 0) return a;
+  else if constexpr (k == 16) return cmk(-a.im, a.re);
+  else if constexpr (k == 32) return cmk(-a.re, -a.im);
+  else if constexpr (k == 48) return cmk(a.im, -a.re);
+  else if constexpr (k % 16 == 8) {  // odd multiples of pi/4
+    constexpr double h = 0.70710678118654752440;
+    if constexpr (k == 8) return cmk(h * (a.re - a.im), h * (a.re + a.im));
+    else if constexpr (k == 24) return cmk(-h * (a.re + a.im), h * (a.re - a.im));
+    else if constexpr (k == 40) return cmk(-h * (a.re - a.im), -h * (a.re + a.im));
+    else return cmk(h * (a.re + a.im), -h * (a.re - a.im));
+  } else {
+    const cplx w = root64(k);
+    return cmul(a, w);
+  }
+}
+
+// Small DFT of size R (power of two <= 16) on registers, natural order in and out.
+// y[k] = sum_n x[n] e^{SIGN 2 pi i n k / R};  SIGN = -1 forward, +1 inverse (unnormalised).
+// Radix-2 decimation in time, fully unrolled; x is read with stride S.
+template <int R, int S, int SIGN>
+struct small_dft {
+  static HD void run(const cplx* x, cplx* y) {
+    if constexpr (R == 1) {
+      y[0] = x[0];
+    } else if constexpr (R == 2) {
+      const cplx a = x[0], b = x[S];
+      y[0] = cadd(a, b); y[1] = csub(a, b);
+    } else {
+      cplx e[R / 2], o[R / 2];
+      small_dft<R / 2, 2 * S, SIGN>::run(x, e);
+      small_dft<R / 2, 2 * S, SIGN>::run(x + S, o);
+      static_for<0, R / 2>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const cplx t = mul_root64<k*(64 / R), SIGN>(o[k]);
+        y[k] = cadd(e[k], t); y[k + R / 2] = csub(e[k], t);
+      });
+    }
+  }
+};
+
+// powers b^0..b^(R-1) of a unit complex number with multiplication depth <= 4
+template <int R>
+HD void unit_powers(cplx b, cplx* pw) {
+  pw[0] = cmk(1.0, 0.0);
+  if constexpr (R > 1) pw[1] = b;
+  if constexpr (R > 2) pw[2] = csqr(b);
+  if constexpr (R > 3) pw[3] = cmul(pw[2], b);
+  if constexpr (R > 4) {
+    pw[4] = csqr(pw[2]);
+    static_for<5, (R < 8 ? R : 8)>([&](auto J) { constexpr int j = decltype(J)::value; pw[j] = cmul(pw[4], pw[j - 4]); });
+  }
+  if constexpr (R > 8) {
+    pw[8] = csqr(pw[4]);
+    static_for<9, R>([&](auto J) { constexpr int j = decltype(J)::value; pw[j] = cmul(pw[8], pw[j - 8]); });
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of the in-place mixed-radix transform for (log2 M, P)
+constexpr int geom_logp(int P) { return P == 16 ? 4 : P == 8 ? 3 : P == 4 ? 2 : -1; }
+constexpr int geom_passes(int LOGM, int P) { return LOGM / geom_logp(P) + ((LOGM % geom_logp(P)) ? 1 : 0); }
+constexpr int geom_radix(int LOGM, int P, int i) {
+  return (i == geom_passes(LOGM, P) - 1 && (LOGM % geom_logp(P))) ? (1 << (LOGM % geom_logp(P))) : P;
+}
+constexpr int geom_weight(int LOGM, int P, int i) {  // W_i = prod_{j>i} R_j
+  int w = 1;
+  for (int j = geom_passes(LOGM, P) - 1; j > i; j--) w *= geom_radix(LOGM, P, j);
+  return w;
+}
+constexpr int geom_tw_offset(int LOGM, int P, int i) {  // pass i < S-1 owns W_i entries e^{-2 pi i m/(W_i R_i)}
+  int o = 0;
+  for (int j = 0; j < i; j++) o += geom_weight(LOGM, P, j);
+  return o;
+}
+
+template <int LOGM, int P>
+struct fft_geom {
+  static constexpr int M = 1 << LOGM;
+  static_assert(geom_logp(P) > 0, "P must be 4, 8 or 16");
+  static constexpr int T = M / P;                        // threads per polynomial
+  static constexpr int S = geom_passes(LOGM, P);         // number of passes
+  static_assert(S >= 2, "need at least two passes");
+  static constexpr int radix(int i) { return geom_radix(LOGM, P, i); }
+  static constexpr int weight(int i) { return geom_weight(LOGM, P, i); }
+  static constexpr int tw_offset(int i) { return geom_tw_offset(LOGM, P, i); }
+  static constexpr int TW_TOTAL = geom_tw_offset(LOGM, P, S - 1);  // then T twist bases e^{i pi t/N}
+  static constexpr int TW_ELEMS = TW_TOTAL + T;
+  // exchange buffer index skew (bank spreading), LDS holds EXCH_ELEMS complex values
+  static HD int skew(int idx) { return idx + (idx >> 4); }
+  static constexpr int EXCH_ELEMS = M + (M >> 4);
+};
+
+// thread t's first point in a radix-R pass of weight W (its points are base + j*W)
+HD int pass_base(int W, int R, int t) { return (t / W) * (W * R) + (t % W); }
+
+// address (before skew) of register j of thread t in pass i
+template <int LOGM, int P, int I>
+HD int pass_addr(int t, int j) {
+  using G = fft_geom<LOGM, P>;
+  constexpr int R = G::radix(I), W = G::weight(I);
+  if constexpr (R == P) return pass_base(W, R, t) + j * W;
+  else return P * t + j;  // last, smaller radix: P contiguous points = P/R small DFTs
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward transform of one polynomial.
+//   v[0..P)   in : folded, UN-twisted points z_n = x_n + i x_{n+M} for n = t + T*j
+//             out: spectrum points at in-place addresses pass_addr<S-1>(t, j)
+//   tw        : table of G::TW_ELEMS entries: pass twiddles, then T twist bases e^{i pi t/N}
+//   exch      : LDS exchange buffer (G::EXCH_ELEMS), shared by the T threads of this polynomial
+//   sync      : barrier for those T threads.  Discipline: write; sync; gather; sync -- so the
+//               buffer is free again when the call returns.
+template <int LOGM, int P, class Sync>
+HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+  using G = fft_geom<LOGM, P>;
+  constexpr int S = G::S;
+  // twist part 1: compile-time factor e^{i pi j T / N} = e^{2 pi i j / (4P)} on register j
+  static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = mul_root64<j*(64 / (4 * P)), +1>(v[j]); });
+  static_for<0, S>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int R = G::radix(i);
+    constexpr int W = G::weight(i);
+    cplx y[P];
+    if constexpr (R == P) {
+      small_dft<P, 1, -1>::run(v, y);
+    } else {
+      static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, -1>::run(v + g * R, y + g * R); });
+    }
+    if constexpr (i < S - 1) {
+      // twiddle e^{-2 pi i k m / (W R)}, m = t % W; pass 0 also carries twist part 2, e^{i pi t / N}
+      const cplx b = tw[G::tw_offset(i) + (t % W)];
+      cplx pw[R];
+      unit_powers<R>(b, pw);
+      if constexpr (i == 0) {
+        const cplx c = tw[G::TW_TOTAL + t];
+        y[0] = cmul(y[0], c);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = cmul(y[k], cmul(pw[k], c)); });
+      } else {
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = cmul(y[k], pw[k]); });
+      }
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+      sync();
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
+      sync();
+    } else {
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = y[j]; });
+    }
+  });
+}
+
+// Inverse transform (unnormalised; the 1/M lives in the Fourier key).
+//   v[0..P)   in : spectrum at addresses pass_addr<S-1>(t, j);  out: z_n for n = t + T*j, twist removed.
+template <int LOGM, int P, class Sync>
+HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+  using G = fft_geom<LOGM, P>;
+  constexpr int S = G::S;
+  static_for<0, S>([&](auto Irev) {
+    constexpr int i = S - 1 - decltype(Irev)::value;
+    constexpr int R = G::radix(i);
+    constexpr int W = G::weight(i);
+    if constexpr (i < S - 1) {
+      const cplx b = tw[G::tw_offset(i) + (t % W)];
+      cplx pw[R];
+      unit_powers<R>(b, pw);
+      if constexpr (i == 0) {
+        const cplx c = tw[G::TW_TOTAL + t];
+        v[0] = cmulc(v[0], c);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; v[k] = cmulc(v[k], cmul(pw[k], c)); });
+      } else {
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; v[k] = cmulc(v[k], pw[k]); });
+      }
+    }
+    cplx y[P];
+    if constexpr (R == P) {
+      small_dft<P, 1, +1>::run(v, y);
+    } else {
+      static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v + g * R, y + g * R); });
+    }
+    if constexpr (i > 0) {
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+      sync();
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
+      sync();
+    } else {
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = mul_root64<j*(64 / (4 * P)), -1>(y[j]); });
+    }
+  });
+}
+
+// host-side fill of the twiddle table (G::TW_ELEMS entries)
+template <int LOGM, int P>
+inline void fill_twiddles(cplx* tw) {
+  using G = fft_geom<LOGM, P>;
+  const long double PI = 3.141592653589793238462643383279502884L;
+  for (int i = 0; i + 1 < G::S; i++) {
+    const int W = geom_weight(LOGM, P, i), R = geom_radix(LOGM, P, i);
+    for (int m = 0; m < W; m++) {
+      const long double a = -2.0L * PI * m / ((long double)W * R);
+      tw[geom_tw_offset(LOGM, P, i) + m] = cmk((double)__builtin_cosl(a), (double)__builtin_sinl(a));
+    }
+  }
+  for (int t = 0; t < G::T; t++) {
+    const long double a = PI * t / (long double)(2 * G::M);
+    tw[G::TW_TOTAL + t] = cmk((double)__builtin_cosl(a), (double)__builtin_sinl(a));
+  }
+}
+
+// double -> torus (mod 2^64), exact for |d| < 2^116
+HD uint64_t f64_to_torus(double d) {
+  const double q = __builtin_rint(d * 5.421010862427522170037e-20);  // 2^-64
+  double r = __builtin_fma(-q, 18446744073709551616.0, d);           // in [-2^63, 2^63]
+  if (r >= 9223372036854775808.0) r -= 18446744073709551616.0;
+  return (uint64_t)(int64_t)r;
+}
+
+}  // namespace dctfhe

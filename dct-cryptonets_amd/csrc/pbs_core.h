@@ -1,0 +1,175 @@
+// pbs_core.h -- the per-thread program of the programmable bootstrap (K4 mod-switch, K5 blind
+// rotate, K6 sample extract of DESIGN.md), written once for the gfx950 kernel and for the host
+// emulator in tests/emul.  Semantics follow oracle/tfhe_ref.h (which cites the reference call
+// site homomorphic_eval.py:70 this replaces).
+//
+// One "group" of T = N/(2P) threads owns one ciphertext for the whole blind rotation:
+//   * the GLWE accumulator ACC (k+1 polynomials, u64) lives in registers,
+//       acc[p][r], r < 2P, is coefficient  c = t + T*r  of polynomial p
+//     (r < P is the low half n = t + T*r, r >= P the high half n + M: exactly the pair a folded
+//      complex point needs);
+//   * a rotation X^a * ACC is a permutation across threads, done through the LDS `stage` array;
+//   * the FFTs exchange through the LDS `exch` array (fft_core.h);
+//   * the Fourier bootstrapping key is streamed from global memory (L2 / Infinity Cache), laid out
+//     [i][row][q][j][t] so that a wave reads 1 KiB contiguous per instruction.
+#pragma once
+#include "fft_core.h"
+
+namespace dctfhe {
+
+template <int LOGN, int K, int L, int P>
+struct pbs_geom {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int LOGM = LOGN - 1;
+  static constexpr int M = N / 2;
+  using F = fft_geom<LOGM, P>;
+  static constexpr int T = F::T;
+  static constexpr int ROWS = (K + 1) * L;
+  static constexpr size_t BSK_ELEMS_PER_KEYBIT = (size_t)ROWS * (K + 1) * M;  // complex
+  // LDS per group (bytes)
+  static constexpr int STAGE_BYTES = N * 8;
+  static constexpr int EXCH_BYTES = F::EXCH_ELEMS * 16;
+  static constexpr int TW_BYTES = F::TW_ELEMS * 16;  // shared by all groups of a workgroup
+};
+
+// signed gadget decomposition, closest-representable rounding; digs[lev], lev 0 most significant
+template <int L>
+HD void decompose(uint64_t v, int beta, int32_t* digs) {
+  const int total = L * beta;
+  uint64_t x = (v + (1ULL << (63 - total))) >> (64 - total);
+  const uint64_t B = 1ULL << beta, half = B >> 1, mask = B - 1;
+  uint64_t carry = 0;
+  static_for<0, L>([&](auto Lv) {
+    constexpr int lev = L - 1 - decltype(Lv)::value;
+    uint64_t d = (x & mask) + carry;
+    x >>= beta;
+    const bool hi = d >= half;
+    digs[lev] = (int32_t)((int64_t)d - (hi ? (int64_t)B : 0));
+    carry = hi ? 1 : 0;
+  });
+}
+
+// test-vector coefficient j (0 <= j < N) of the table T (2^w entries)
+HD uint64_t testvec_coeff(const int64_t* table, int w, int N, int j) {
+  const int box = N >> w, half = box >> 1;
+  const int jj = j + half;
+  return (jj < N) ? (uint64_t)table[jj / box] : (uint64_t)0 - (uint64_t)table[0];
+}
+
+struct pbs_args {
+  const uint64_t* ct_small;   // this ciphertext: n+1 words
+  int n;
+  int beta;
+  const cplx* bsk;            // Fourier key, [n][ROWS][K+1][P][T] complex, 1/M folded in
+  const int64_t* table;       // 2^w entries, output encoding
+  int w;
+  uint64_t* out;              // D_out+1 words
+  int D_out;
+  int accumulate;             // 0: out = extract(ACC) (mask beyond K*N zeroed); 1: out += extract(ACC)
+  uint64_t body_add;          // added to the body word (accumulate mode: the "- v" of a bit step)
+};
+
+// The whole bootstrap for one ciphertext, executed by thread t of its group.
+template <int LOGN, int K, int L, int P, class Sync>
+HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, Sync&& sync) {
+  using G = pbs_geom<LOGN, K, L, P>;
+  constexpr int N = G::N, M = G::M, T = G::T;
+  const int n = A.n;
+  const int msh = 64 - LOGN - 2;
+
+  uint64_t acc[K + 1][2 * P];
+  {  // ACC = X^{-b~} * TV (trivial GLWE)
+    const uint32_t bt = (uint32_t)(((A.ct_small[n] >> msh) + 1) >> 1) & (2 * N - 1);
+    static_for<0, K>([&](auto Pp) { constexpr int p = decltype(Pp)::value; static_for<0, 2 * P>([&](auto R) { acc[p][decltype(R)::value] = 0; }); });
+    static_for<0, 2 * P>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      const uint32_t idx = ((uint32_t)(t + T * r) + bt) & (2 * N - 1);
+      const uint64_t v = testvec_coeff(A.table, A.w, N, (int)(idx & (N - 1)));
+      acc[K][r] = (idx & N) ? (uint64_t)0 - v : v;
+    });
+  }
+
+  for (int i = 0; i < n; i++) {
+    const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
+    const cplx* bsk_i = A.bsk + (size_t)i * G::BSK_ELEMS_PER_KEYBIT;
+    cplx out[K + 1][P];
+    static_for<0, K + 1>([&](auto Q) { static_for<0, P>([&](auto J) { out[decltype(Q)::value][decltype(J)::value] = cmk(0.0, 0.0); }); });
+
+    static_for<0, K + 1>([&](auto Pp) {
+      constexpr int p = decltype(Pp)::value;
+      // rotate polynomial p through LDS
+      static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[t + T * r] = acc[p][r]; });
+      sync();
+      int32_t dig[2 * P][L];
+      static_for<0, 2 * P>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
+        uint64_t v = stage[src & (N - 1)];
+        if (src & N) v = (uint64_t)0 - v;
+        decompose<L>(v - acc[p][r], A.beta, dig[r]);
+      });
+      sync();
+      static_for<0, L>([&](auto Lv) {
+        constexpr int lev = decltype(Lv)::value;
+        cplx v[P];
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = cmk((double)dig[j][lev], (double)dig[P + j][lev]); });
+        fft_forward<G::LOGM, P>(v, t, tw, exch, sync);
+        const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
+        static_for<0, K + 1>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          static_for<0, P>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            out[q][j] = cfma(v[j], row[(size_t)q * M + j * T + t], out[q][j]);
+          });
+        });
+      });
+    });
+
+    static_for<0, K + 1>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      fft_inverse<G::LOGM, P>(out[q], t, tw, exch, sync);
+      static_for<0, P>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        acc[q][j] += f64_to_torus(out[q][j].re);
+        acc[q][P + j] += f64_to_torus(out[q][j].im);
+      });
+    });
+  }
+
+  // sample extract (coefficient 0) straight into the output LWE ciphertext
+  uint64_t* o = A.out;
+  static_for<0, K>([&](auto Pp) {
+    constexpr int p = decltype(Pp)::value;
+    static_for<0, 2 * P>([&](auto R) {
+      constexpr int r = decltype(R)::value;
+      const int c = t + T * r;
+      const int dst = p * N + (c == 0 ? 0 : N - c);
+      const uint64_t v = (c == 0) ? acc[p][r] : (uint64_t)0 - acc[p][r];
+      if (A.accumulate) o[dst] += v; else o[dst] = v;
+    });
+  });
+  if (!A.accumulate)
+    for (int j = K * N + t; j < A.D_out; j += T) o[j] = 0;
+  if (t == 0) {
+    if (A.accumulate) o[A.D_out] += acc[K][0] + A.body_add; else o[A.D_out] = acc[K][0] + A.body_add;
+  }
+}
+
+// Forward transform of one standard-domain key polynomial into the device layout [j][t], with
+// the 1/M of the inverse transform folded in.  Thread t of a T-thread group.
+template <int LOGN, int P, class Sync>
+HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  using F = fft_geom<LOGN - 1, P>;
+  constexpr int T = F::T;
+  cplx v[P];
+  static_for<0, P>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    v[j] = cmk((double)(int64_t)poly[t + T * j], (double)(int64_t)poly[t + T * j + M]);
+  });
+  fft_forward<LOGN - 1, P>(v, t, tw, exch, sync);
+  const double inv = 1.0 / (double)M;
+  static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; dst[j * T + t] = cmk(v[j].re * inv, v[j].im * inv); });
+}
+
+}  // namespace dctfhe

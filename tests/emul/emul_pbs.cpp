@@ -1,0 +1,151 @@
+// Host emulation of the blind-rotate thread program (dct-cryptonets_amd/csrc/pbs_core.h):
+// T std::threads play the T lanes of one ciphertext group, a std::barrier plays s_barrier,
+// a heap array plays LDS.  Checks the FFT index math and the whole PBS against the CPU
+// oracle (oracle/tfhe_ref.c) without a GPU.  Test infrastructure only.
+#include <barrier>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../dct-cryptonets_amd/csrc/pbs_core.h"
+#include "../../oracle/tfhe_ref.h"
+
+using namespace dctfhe;
+
+template <int LOGN, int K, int L, int P>
+static int run_case(int n, int beta, int w, double sigma_bsk) {
+  using G = pbs_geom<LOGN, K, L, P>;
+  constexpr int N = G::N, M = G::M, T = G::T;
+  const int D = K * N, count = 6;
+  std::vector<uint8_t> S(D), s(n);
+  ref_gen_binary_key(11, D, S.data());
+  ref_gen_binary_key(12, n, s.data());
+  const int rows = (K + 1) * L;
+  std::vector<uint64_t> bsk((size_t)n * rows * (K + 1) * N);
+  ref_bsk_gen(s.data(), n, S.data(), K, N, L, beta, sigma_bsk, 13, bsk.data());
+  std::vector<double> bskf(bsk.size());
+  ref_bsk_to_fourier(bsk.data(), n, K, N, L, bskf.data());
+
+  // inputs: small-LWE encryptions of messages on w bits (+padding)
+  std::vector<uint64_t> phases(count), cts((size_t)count * (n + 1));
+  for (int c = 0; c < count; c++) phases[c] = (uint64_t)((c * 5 + 1) % (1 << w)) << (63 - w);
+  ref_lwe_encrypt_batch(s.data(), n, n, phases.data(), count, 1e-9, 14, cts.data());
+  std::vector<int64_t> table(1 << w);
+  for (int x = 0; x < (1 << w); x++) table[x] = (int64_t)(((x * 3 + 2) % (1 << w))) << (63 - w - 1);
+
+  std::vector<uint64_t> ref_out((size_t)count * (D + 1));
+  ref_pbs_batch(cts.data(), count, n, bskf.data(), bsk.data(), 0, K, N, L, beta, table.data(), w, nullptr, D, ref_out.data());
+
+  // ---- emulated device path
+  std::vector<cplx> tw(G::F::TW_ELEMS);
+  fill_twiddles<G::LOGM, P>(tw.data());
+  std::vector<cplx> bsk_dev((size_t)n * G::BSK_ELEMS_PER_KEYBIT);
+  std::vector<uint64_t> stage(N);
+  std::vector<cplx> exch(G::F::EXCH_ELEMS);
+  std::vector<uint64_t> emu_out((size_t)count * (D + 1), 0x1234);
+  {
+    std::barrier bar(T);
+    auto worker = [&](int t) {
+      auto sync = [&] { bar.arrive_and_wait(); };
+      const size_t npoly = (size_t)n * rows * (K + 1);
+      for (size_t q = 0; q < npoly; q++)
+        key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), exch.data(), sync);
+      for (int c = 0; c < count; c++) {
+        pbs_args A;
+        A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data();
+        A.table = table.data(); A.w = w; A.out = emu_out.data() + (size_t)c * (D + 1); A.D_out = D;
+        A.accumulate = 0; A.body_add = 0;
+        pbs_thread<LOGN, K, L, P>(A, t, tw.data(), stage.data(), exch.data(), sync);
+        sync();
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    for (auto& x : th) x.join();
+  }
+  std::vector<uint64_t> ph_ref(count), ph_emu(count);
+  ref_lwe_phase_batch(S.data(), D, ref_out.data(), count, ph_ref.data());
+  ref_lwe_phase_batch(S.data(), D, emu_out.data(), count, ph_emu.data());
+  int bad = 0;
+  double maxd = 0, maxe = 0;
+  for (int c = 0; c < count; c++) {
+    const int m = (int)(phases[c] >> (63 - w));
+    const uint64_t want = (uint64_t)table[m];
+    const double d = std::fabs((double)(int64_t)(ph_emu[c] - ph_ref[c])) / 18446744073709551616.0;
+    const double e = std::fabs((double)(int64_t)(ph_emu[c] - want)) / 18446744073709551616.0;
+    if (d > maxd) maxd = d;
+    if (e > maxe) maxe = e;
+    const int got = (int)(((ph_emu[c] + (1ULL << (63 - w - 2))) >> (63 - w - 1)) & ((1 << (w + 1)) - 1));
+    if (got != (int)(want >> (63 - w - 1))) bad++;
+  }
+  std::printf("N=%d k=%d l=%d P=%d T=%d n=%d: wrong=%d max|emu-ref|=%.3g max|emu-ideal|=%.3g\n", N, K, L, P, T, n, bad, maxd, maxe);
+  // a rounding flip in one decomposition gives a different but equivalent ciphertext, so the two
+  // implementations agree only up to the scheme's own noise: bound both against the ideal value
+  return bad || maxe > std::ldexp(1.0, -(w + 4));
+}
+
+// pure FFT round trip + comparison with an O(M^2) negacyclic evaluation
+template <int LOGN, int P>
+static int fft_case() {
+  constexpr int N = 1 << LOGN, M = N / 2;
+  using F = fft_geom<LOGN - 1, P>;
+  constexpr int T = F::T;
+  std::vector<cplx> tw(F::TW_ELEMS), exch(F::EXCH_ELEMS);
+  fill_twiddles<LOGN - 1, P>(tw.data());
+  std::vector<double> x(N);
+  uint64_t st = 99;
+  for (auto& v : x) v = (double)((int64_t)(ref_splitmix64(&st) >> 40) - (1 << 23));
+  std::vector<cplx> spec(M), back(M);
+  std::barrier bar(T);
+  auto worker = [&](int t) {
+    auto sync = [&] { bar.arrive_and_wait(); };
+    cplx v[P];
+    for (int j = 0; j < P; j++) v[j] = cmk(x[t + T * j], x[t + T * j + M]);
+    fft_forward<LOGN - 1, P>(v, t, tw.data(), exch.data(), sync);
+    for (int j = 0; j < P; j++) spec[j * T + t] = v[j];
+    fft_inverse<LOGN - 1, P>(v, t, tw.data(), exch.data(), sync);
+    for (int j = 0; j < P; j++) back[t + T * j] = v[j];
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+  for (auto& z : th) z.join();
+  double err = 0;
+  for (int n = 0; n < M; n++) {
+    err = std::fmax(err, std::fabs(back[n].re / M - x[n]));
+    err = std::fmax(err, std::fabs(back[n].im / M - x[n + M]));
+  }
+  // spectrum must be a permutation of the evaluations at the roots e^{i pi (1-4k)/N}
+  double serr = 0;
+  std::vector<char> used(M, 0);
+  const double PI = 3.14159265358979323846;
+  for (int k = 0; k < M; k++) {
+    double re = 0, im = 0;
+    for (int n = 0; n < N; n++) { const double a = PI * (double)n * (1.0 - 4.0 * k) / N; re += x[n] * std::cos(a); im += x[n] * std::sin(a); }
+    double best = 1e300; int bi = -1;
+    for (int q = 0; q < M; q++) { const double d = std::hypot(spec[q].re - re, spec[q].im - im); if (d < best) { best = d; bi = q; } }
+    if (used[bi]) serr = 1e300;
+    used[bi] = 1;
+    serr = std::fmax(serr, best);
+  }
+  std::printf("fft N=%d P=%d T=%d passes=%d: roundtrip err=%.3g spectrum err=%.3g\n", N, P, T, F::S, err, serr);
+  return err > 1e-6 || serr > 1e-3;
+}
+
+int main() {
+  int fail = 0;
+  fail |= fft_case<8, 16>();
+  fail |= fft_case<9, 8>();
+  fail |= fft_case<9, 16>();
+  fail |= fft_case<10, 16>();
+  fail |= fft_case<10, 8>();
+  fail |= fft_case<11, 16>();
+  fail |= run_case<8, 1, 2, 16>(20, 10, 3, 1e-12);
+  fail |= run_case<9, 2, 1, 8>(16, 16, 3, 1e-13);
+  fail |= run_case<9, 1, 3, 8>(16, 7, 4, 1e-12);
+  fail |= run_case<10, 1, 2, 16>(12, 12, 4, 1e-13);
+  std::printf(fail ? "EMUL FAIL\n" : "EMUL OK\n");
+  return fail;
+}
