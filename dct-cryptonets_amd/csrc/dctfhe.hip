@@ -1,0 +1,908 @@
+// dctfhe.hip -- host side of libdctfhe.so: contexts, key generation, the layer scheduler that walks a
+// compiled circuit and issues batched HIP launches, and the C ABI of include/dctfhe.h.
+// gfx950 only.  No CPU fallback anywhere: every entry point needs a live HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dctfhe.h"
+#include "kernels.h"
+
+using namespace dctfhe;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) return fail("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+  } while (0)
+#define CHK(x)              \
+  do {                      \
+    int r_ = (x);           \
+    if (r_ != 0) return r_; \
+  } while (0)
+
+extern "C" const char* dctfhe_last_error(void) { return g_err.c_str(); }
+extern "C" int dctfhe_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------ structs
+struct dctfhe_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, own = nullptr;
+  hipDeviceProp_t prop;
+};
+
+struct TierKeys {
+  dctfhe_tier t{};
+  uint64_t* d_ksk = nullptr;     // [D][lk][n+1]
+  uint64_t* d_colsum = nullptr;  // [n+1]
+  bool own_ksk = false;
+  cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]
+  cplx* d_tw = nullptr;
+};
+
+struct dctfhe_keys {
+  dctfhe_ctx* ctx = nullptr;
+  dctfhe_params p{};
+  uint64_t seed = 0;
+  uint8_t *d_S = nullptr, *d_s = nullptr;
+  TierKeys tiers[DCTFHE_MAX_TIERS];
+  uint64_t* d_dummy = nullptr;   // D+1 words, sink of padded bootstrap groups
+};
+
+enum { OP_CONV = 1, OP_ADD = 2, OP_SUMPOOL = 3, OP_LUT = 4 };
+struct Op {
+  int32_t type, src0, src1, dst;
+  int32_t ip[12];
+  int64_t lp[2];
+  int64_t payload_off, payload_len;
+};
+struct TensorShape { int32_t C, H, W, pad; };
+
+struct dctfhe_circuit {
+  dctfhe_ctx* ctx = nullptr;
+  std::vector<TensorShape> tensors;
+  std::vector<Op> ops;
+  std::vector<void*> d_payload;  // per op, device copy of its payload (weights / tables)
+  int input_tensor = 0, output_tensor = 0, max_bit_width = 0;
+};
+
+struct dctfhe_session {
+  dctfhe_ctx* ctx = nullptr;
+  dctfhe_circuit* circ = nullptr;
+  dctfhe_keys* keys = nullptr;  // nullptr: clear mode (D = 0)
+  int batch = 0;
+  int D = 0;
+  std::vector<uint64_t*> d_tensor;
+  std::vector<std::pair<size_t, uint64_t*>> owned;
+  std::vector<size_t> tensor_words;
+  // scratch for LUT sites
+  size_t chunk = 0;
+  uint8_t* d_digits = nullptr;
+  uint64_t* d_bodies = nullptr;
+  uint64_t* d_small = nullptr;
+  int64_t* d_bit_tables = nullptr;  // 64 single-entry tables: 2^j
+  int* d_overflow = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------ kernel dispatch
+// (logN, k, l, points per thread).  GROUPS is chosen so that a workgroup has 256 threads.
+#define PBS_CASES(X)                                                                                 \
+  X(8, 1, 1, 16) X(8, 1, 2, 16) X(8, 2, 2, 8) X(9, 1, 2, 16) X(9, 2, 1, 8) X(9, 1, 3, 8) X(9, 3, 2, 8)  \
+  X(10, 1, 1, 16) X(10, 1, 2, 16) X(10, 2, 1, 8) X(10, 2, 2, 8) X(10, 1, 3, 16)                      \
+  X(11, 1, 1, 16) X(11, 1, 2, 16) X(11, 1, 3, 16) X(12, 1, 1, 16) X(12, 1, 2, 16) X(12, 1, 3, 16)   \
+  X(13, 1, 1, 16) X(13, 1, 2, 16) X(13, 1, 3, 16)
+
+template <int LOGN, int P>
+constexpr int groups_for() {
+  constexpr int T = fft_geom<LOGN - 1, P>::T;
+  return T >= 256 ? 1 : 256 / T;
+}
+
+static int tier_ppt(const dctfhe_tier& t) {
+#define X(LN, K_, L_, P_) if (t.logN == LN && t.k == K_ && t.l == L_) return P_;
+  PBS_CASES(X)
+#undef X
+  return 0;
+}
+
+static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st) {
+  if (a.count == 0) return 0;
+#define X(LN, K_, L_, P_)                                                                            \
+  if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
+    using G = pbs_geom<LN, K_, L_, P_>;                                                              \
+    constexpr int GR = groups_for<LN, P_>();                                                         \
+    const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES);                  \
+    static bool attr_done = false;                                                                   \
+    if (!attr_done) {                                                                                \
+      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, K_, L_, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr_done = true;                                                                              \
+    }                                                                                                \
+    const unsigned grid = (unsigned)((a.count + GR - 1) / GR);                                       \
+    hipLaunchKernelGGL((pbs_kernel<LN, K_, L_, P_, GR>), dim3(grid), dim3(G::T * GR), lds, st, a);   \
+    HIPCHK(hipGetLastError());                                                                       \
+    return 0;                                                                                        \
+  }
+  PBS_CASES(X)
+#undef X
+  return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d", t.logN, t.k, t.l);
+}
+
+static int make_twiddles(const dctfhe_tier& t, std::vector<cplx>& tw) {
+#define X(LN, K_, L_, P_)                                        \
+  if (t.logN == LN && t.k == K_ && t.l == L_) {                  \
+    tw.resize(fft_geom<LN - 1, P_>::TW_ELEMS);                   \
+    fill_twiddles<LN - 1, P_>(tw.data());                        \
+    return 0;                                                    \
+  }
+  PBS_CASES(X)
+#undef X
+  return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d", t.logN, t.k, t.l);
+}
+
+static int launch_bsk_fourier(const dctfhe_tier& t, const uint64_t* polys, size_t npoly, const cplx* tw, cplx* out, hipStream_t st) {
+#define X(LN, K_, L_, P_)                                                                            \
+  if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
+    using F = fft_geom<LN - 1, P_>;                                                                  \
+    constexpr int GR = groups_for<LN, P_>();                                                         \
+    const size_t lds = (size_t)F::TW_ELEMS * 16 + (size_t)GR * F::EXCH_ELEMS * 16;                   \
+    static bool attr_done = false;                                                                   \
+    if (!attr_done) {                                                                                \
+      HIPCHK(hipFuncSetAttribute((const void*)k_bsk_fourier<LN, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr_done = true;                                                                              \
+    }                                                                                                \
+    const unsigned grid = (unsigned)((npoly + GR - 1) / GR);                                         \
+    hipLaunchKernelGGL((k_bsk_fourier<LN, P_, GR>), dim3(grid), dim3(F::T * GR), lds, st, polys, npoly, tw, out); \
+    HIPCHK(hipGetLastError());                                                                       \
+    return 0;                                                                                        \
+  }
+  PBS_CASES(X)
+#undef X
+  return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d", t.logN, t.k, t.l);
+}
+
+// ------------------------------------------------------------------------------------------ context
+extern "C" int dctfhe_ctx_create(int device_id, dctfhe_ctx** out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail("dctfhe: no HIP device visible -- this engine has no CPU path");
+  if (device_id < 0 || device_id >= ndev) return fail("dctfhe: device %d out of range (%d visible)", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  auto* c = new dctfhe_ctx;
+  c->device = device_id;
+  HIPCHK(hipGetDeviceProperties(&c->prop, device_id));
+  HIPCHK(hipStreamCreate(&c->own));
+  c->stream = c->own;
+  *out = c;
+  return 0;
+}
+extern "C" int dctfhe_ctx_destroy(dctfhe_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  if (c->own) hipStreamDestroy(c->own);
+  delete c;
+  return 0;
+}
+extern "C" int dctfhe_ctx_set_stream(dctfhe_ctx* c, void* s) {
+  c->stream = s ? (hipStream_t)s : c->own;
+  return 0;
+}
+extern "C" int dctfhe_ctx_synchronize(dctfhe_ctx* c) {
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ keygen
+static int check_params(const dctfhe_params* p) {
+  if (p->n_tiers < 1 || p->n_tiers > DCTFHE_MAX_TIERS) return fail("n_tiers out of range");
+  if (p->D < 4 || p->D % 4) return fail("D must be a positive multiple of 4");
+  for (int i = 0; i < p->n_tiers; i++) {
+    const dctfhe_tier& t = p->tiers[i];
+    if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
+    if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
+    if (t.l * t.beta > 63 || t.l < 1) return fail("tier %d: bad bootstrap gadget", i);
+    if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
+    if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
+    if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);
+    if (t.ksk_share >= 0) {
+      const dctfhe_tier& o = p->tiers[t.ksk_share];
+      if (o.n != t.n || o.lk != t.lk || o.betak != t.betak) return fail("tier %d: shared key-switch key has another shape", i);
+    }
+  }
+  return 0;
+}
+
+static int gen_bsk_std_chunk(dctfhe_keys* K, int tier, int i0, int ni, uint64_t* d_out) {
+  const dctfhe_tier& t = K->p.tiers[tier];
+  const int N = 1 << t.logN, rows = (t.k + 1) * t.l;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_bsk_gen_std, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, K->ctx->stream, K->d_s, K->d_S, i0, t.k, N,
+                     t.l, t.beta, t.glwe_sigma, K->seed, (uint64_t)(STREAM_BSK_MASK + 2 * tier), d_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint64_t seed, dctfhe_keys** out) {
+  CHK(check_params(params));
+  HIPCHK(hipSetDevice(ctx->device));
+  auto* K = new dctfhe_keys;
+  K->ctx = ctx; K->p = *params; K->seed = seed;
+  hipStream_t st = ctx->stream;
+  const int D = params->D;
+  HIPCHK(hipMalloc(&K->d_S, D));
+  HIPCHK(hipMalloc(&K->d_s, params->n_max));
+  HIPCHK(hipMalloc(&K->d_dummy, (size_t)(D + 1) * 8));
+  hipLaunchKernelGGL(k_gen_bits, dim3((D + 255) / 256), dim3(256), 0, st, seed, (uint64_t)STREAM_BIGKEY, K->d_S, D);
+  hipLaunchKernelGGL(k_gen_bits, dim3((params->n_max + 255) / 256), dim3(256), 0, st, seed, (uint64_t)STREAM_SMALLKEY, K->d_s, params->n_max);
+  HIPCHK(hipGetLastError());
+  for (int ti = 0; ti < params->n_tiers; ti++) {
+    const dctfhe_tier& t = params->tiers[ti];
+    TierKeys& tk = K->tiers[ti];
+    tk.t = t;
+    // key-switch key
+    if (t.ksk_share >= 0) {
+      tk.d_ksk = K->tiers[t.ksk_share].d_ksk;
+      tk.d_colsum = K->tiers[t.ksk_share].d_colsum;
+    } else {
+      const size_t rows = (size_t)D * t.lk;
+      HIPCHK(hipMalloc(&tk.d_ksk, rows * (t.n + 1) * 8));
+      HIPCHK(hipMalloc(&tk.d_colsum, (size_t)(t.n + 1) * 8));
+      tk.own_ksk = true;
+      hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)rows), dim3(256), 0, st, K->d_S, K->d_s, t.n, t.lk, t.betak, t.lwe_sigma, seed,
+                         (uint64_t)(STREAM_KSK + 2 * ti), tk.d_ksk);
+      hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.d_colsum);
+      HIPCHK(hipGetLastError());
+    }
+    // twiddles + Fourier bootstrap key
+    std::vector<cplx> tw;
+    CHK(make_twiddles(t, tw));
+    HIPCHK(hipMalloc(&tk.d_tw, tw.size() * sizeof(cplx)));
+    HIPCHK(hipMemcpyAsync(tk.d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int N = 1 << t.logN, M = N / 2, rows = (t.k + 1) * t.l;
+    const size_t per_bit_polys = (size_t)rows * (t.k + 1);
+    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)t.n * per_bit_polys * M * sizeof(cplx)));
+    const int chunk = std::max(1, (int)std::min<size_t>(t.n, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
+    uint64_t* d_std = nullptr;
+    HIPCHK(hipMalloc(&d_std, (size_t)chunk * per_bit_polys * N * 8));
+    for (int i0 = 0; i0 < t.n; i0 += chunk) {
+      const int ni = std::min(chunk, t.n - i0);
+      CHK(gen_bsk_std_chunk(K, ti, i0, ni, d_std));
+      CHK(launch_bsk_fourier(t, d_std, (size_t)ni * per_bit_polys, tk.d_tw, tk.d_bsk + (size_t)i0 * per_bit_polys * M, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d_std));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  *out = K;
+  return 0;
+}
+
+extern "C" int dctfhe_keys_destroy(dctfhe_keys* K) {
+  if (!K) return 0;
+  hipSetDevice(K->ctx->device);
+  hipFree(K->d_S); hipFree(K->d_s); hipFree(K->d_dummy);
+  for (int i = 0; i < K->p.n_tiers; i++) {
+    if (K->tiers[i].own_ksk) { hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); }
+    hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw);
+  }
+  delete K;
+  return 0;
+}
+
+extern "C" int dctfhe_keys_export_secret(dctfhe_keys* K, uint8_t* big_key, uint8_t* small_key) {
+  HIPCHK(hipSetDevice(K->ctx->device));
+  HIPCHK(hipMemcpy(big_key, K->d_S, K->p.D, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(small_key, K->d_s, K->p.n_max, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int dctfhe_keys_export_ksk(dctfhe_keys* K, int tier, uint64_t* out) {
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  const dctfhe_tier& t = K->p.tiers[tier];
+  HIPCHK(hipSetDevice(K->ctx->device));
+  HIPCHK(hipMemcpy(out, K->tiers[tier].d_ksk, (size_t)K->p.D * t.lk * (t.n + 1) * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int dctfhe_keys_export_bsk(dctfhe_keys* K, int tier, uint64_t* out) {
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  const dctfhe_tier& t = K->p.tiers[tier];
+  HIPCHK(hipSetDevice(K->ctx->device));
+  const int N = 1 << t.logN;
+  const size_t words = (size_t)t.n * (t.k + 1) * t.l * (t.k + 1) * N;
+  uint64_t* d = nullptr;
+  HIPCHK(hipMalloc(&d, words * 8));
+  CHK(gen_bsk_std_chunk(K, tier, 0, t.n, d));
+  HIPCHK(hipStreamSynchronize(K->ctx->stream));
+  HIPCHK(hipMemcpy(out, d, words * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ client ops
+extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* phases, size_t count, uint64_t seed, uint64_t* cts) {
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int D = K->p.D;
+  uint64_t *d_ph = nullptr, *d_ct = nullptr;
+  HIPCHK(hipMalloc(&d_ph, count * 8));
+  HIPCHK(hipMalloc(&d_ct, count * (size_t)(D + 1) * 8));
+  HIPCHK(hipMemcpyAsync(d_ph, phases, count * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, D, d_ph, K->p.input_sigma, seed, d_ct);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(cts, d_ct, count * (size_t)(D + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_ph); hipFree(d_ct);
+  return 0;
+}
+extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* cts, size_t count, uint64_t* phases) {
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int D = K->p.D;
+  uint64_t *d_ph = nullptr, *d_ct = nullptr;
+  HIPCHK(hipMalloc(&d_ph, count * 8));
+  HIPCHK(hipMalloc(&d_ct, count * (size_t)(D + 1) * 8));
+  HIPCHK(hipMemcpyAsync(d_ct, cts, count * (size_t)(D + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_lwe_phase, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, d_ct, d_ph);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(phases, d_ph, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_ph); hipFree(d_ct);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ device-level building blocks
+struct Timers {
+  hipStream_t st;
+  bool on;
+  struct Span { hipEvent_t a, b; int cat; };
+  std::vector<Span> spans;
+  int begin(int cat) {
+    if (!on) return -1;
+    Span s; s.cat = cat;
+    hipEventCreate(&s.a); hipEventCreate(&s.b);
+    hipEventRecord(s.a, st);
+    spans.push_back(s);
+    return (int)spans.size() - 1;
+  }
+  void end(int h) { if (h >= 0) hipEventRecord(spans[h].b, st); }
+};
+enum { CAT_LINEAR = 100, CAT_KS = 101 };  // 0..7: bootstrap of tier i
+
+// key switch of `count` ciphertexts (D+1 words each) into small ciphertexts of tier `tier`
+static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t count, int shift, uint8_t* d_digits, uint64_t* d_bodies,
+                         uint64_t* d_small, Timers* tm) {
+  const dctfhe_tier& t = K->p.tiers[tier];
+  const TierKeys& tk = K->tiers[tier];
+  const int D = K->p.D;
+  hipStream_t st = K->ctx->stream;
+  const int h = tm ? tm->begin(CAT_KS) : -1;
+  const size_t total = count * (size_t)D;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, D, shift, t.lk, t.betak, d_digits, d_bodies);
+  constexpr int CT = 16;
+  dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));
+  hipLaunchKernelGGL(k_ks_gemm<CT>, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_ksk, tk.d_colsum, t.n, t.betak, d_small);
+  HIPCHK(hipGetLastError());
+  if (tm) tm->end(h);
+  return 0;
+}
+
+static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t count, const int64_t* d_tables, int w, const int32_t* d_idx,
+                   int hw, int nchan, size_t e_offset, uint64_t* d_out, int accumulate, uint64_t body_add, Timers* tm) {
+  const dctfhe_tier& t = K->p.tiers[tier];
+  pbs_launch a;
+  a.cts_small = d_small; a.count = count; a.n = t.n; a.beta = t.beta;
+  a.bsk = K->tiers[tier].d_bsk; a.tw = K->tiers[tier].d_tw;
+  a.tables = d_tables; a.w = w; a.table_idx = d_idx; a.hw = hw; a.nchan = nchan; a.e_offset = e_offset;
+  a.out = d_out; a.D_out = K->p.D; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy;
+  const int h = tm ? tm->begin(tier) : -1;
+  CHK(launch_pbs(t, a, K->ctx->stream));
+  if (tm) tm->end(h);
+  return 0;
+}
+
+static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t L, const int8_t* d_w, int Cout, int KH,
+                      int KW, int stride, int pad, uint64_t* out) {
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  constexpr int COT = 16;
+  dim3 grid((unsigned)((L + 255) / 256), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + COT - 1) / COT));
+  hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, L, d_w, Cout, KH, KW, stride, pad, Ho, Wo, out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 16384)); }
+
+// exact rounding + table look-up on `count` ciphertexts, in place on d_work (already shifted / offset)
+struct LutScratch { uint8_t* digits; uint64_t* bodies; uint64_t* small; int64_t* bit_tables; size_t chunk; };
+static int dev_round_lut(dctfhe_keys* K, int bit_tier, int tab_tier, uint64_t* d_work, size_t count, int p, int r, const int64_t* d_tables,
+                         int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm) {
+  const size_t L = (size_t)K->p.D + 1;
+  for (size_t c0 = 0; c0 < count; c0 += sc.chunk) {
+    const size_t cn = std::min(sc.chunk, count - c0);
+    uint64_t* w0 = d_work + c0 * L;
+    for (int i = 0; i < r; i++) {
+      CHK(dev_keyswitch(K, bit_tier, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm));
+      const int vlog = 62 - p + i;
+      CHK(dev_pbs(K, bit_tier, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm));
+    }
+    CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm));
+    CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm));
+  }
+  return 0;
+}
+
+static int alloc_lut_scratch(dctfhe_keys* K, size_t chunk, LutScratch* sc) {
+  int lkmax = 1, nmax = 1;
+  for (int i = 0; i < K->p.n_tiers; i++) { lkmax = std::max(lkmax, K->p.tiers[i].lk); nmax = std::max(nmax, K->p.tiers[i].n); }
+  sc->chunk = chunk;
+  HIPCHK(hipMalloc(&sc->digits, chunk * (size_t)K->p.D * lkmax));
+  HIPCHK(hipMalloc(&sc->bodies, chunk * 8));
+  HIPCHK(hipMalloc(&sc->small, chunk * (size_t)(nmax + 1) * 8));
+  HIPCHK(hipMalloc(&sc->bit_tables, 64 * 8));
+  int64_t bt[64];
+  for (int j = 0; j < 64; j++) bt[j] = (int64_t)(1ULL << j);
+  HIPCHK(hipMemcpy(sc->bit_tables, bt, sizeof bt, hipMemcpyHostToDevice));
+  return 0;
+}
+static void free_lut_scratch(LutScratch* sc) {
+  hipFree(sc->digits); hipFree(sc->bodies); hipFree(sc->small); hipFree(sc->bit_tables);
+}
+
+// ------------------------------------------------------------------------------------------ primitives on host buffers
+extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, uint64_t* cts_small) {
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const dctfhe_tier& t = K->p.tiers[tier];
+  const size_t L = (size_t)K->p.D + 1;
+  uint64_t *d_in, *d_small, *d_bodies; uint8_t* d_dig;
+  HIPCHK(hipMalloc(&d_in, count * L * 8));
+  HIPCHK(hipMalloc(&d_small, count * (size_t)(t.n + 1) * 8));
+  HIPCHK(hipMalloc(&d_bodies, count * 8));
+  HIPCHK(hipMalloc(&d_dig, count * (size_t)K->p.D * t.lk));
+  HIPCHK(hipMemcpy(d_in, cts, count * L * 8, hipMemcpyHostToDevice));
+  CHK(dev_keyswitch(K, tier, d_in, count, shift, d_dig, d_bodies, d_small, nullptr));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cts_small, d_small, count * (size_t)(t.n + 1) * 8, hipMemcpyDeviceToHost));
+  hipFree(d_in); hipFree(d_small); hipFree(d_bodies); hipFree(d_dig);
+  return 0;
+}
+
+extern "C" int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts_small, size_t count, const int64_t* tables, int ntab,
+                          int w, const int32_t* table_idx, uint64_t* cts_out) {
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const dctfhe_tier& t = K->p.tiers[tier];
+  if (w > t.logN - 1) return fail("table of 2^%d entries does not fit N = 2^%d", w, t.logN);
+  const size_t L = (size_t)K->p.D + 1;
+  uint64_t *d_small, *d_out; int64_t* d_tab; int32_t* d_idx = nullptr;
+  HIPCHK(hipMalloc(&d_small, count * (size_t)(t.n + 1) * 8));
+  HIPCHK(hipMalloc(&d_out, count * L * 8));
+  HIPCHK(hipMalloc(&d_tab, ((size_t)ntab << w) * 8));
+  HIPCHK(hipMemcpy(d_small, cts_small, count * (size_t)(t.n + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_tab, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
+  if (table_idx) {
+    HIPCHK(hipMalloc(&d_idx, count * 4));
+    HIPCHK(hipMemcpy(d_idx, table_idx, count * 4, hipMemcpyHostToDevice));
+  }
+  CHK(dev_pbs(K, tier, d_small, count, d_tab, w, d_idx, 1, 1, 0, d_out, 0, 0, nullptr));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cts_out, d_out, count * L * 8, hipMemcpyDeviceToHost));
+  hipFree(d_small); hipFree(d_out); hipFree(d_tab); if (d_idx) hipFree(d_idx);
+  return 0;
+}
+
+extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_keys* K, int bit_tier, int tab_tier, const uint64_t* cts, size_t count, int p, int r,
+                                const int64_t* tables, int ntab, int w, const int32_t* table_idx, uint64_t* cts_out) {
+  if (tab_tier < 0 || tab_tier >= K->p.n_tiers || (r > 0 && (bit_tier < 0 || bit_tier >= K->p.n_tiers))) return fail("tier out of range");
+  if (w != p - r) return fail("w must equal p - r");
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t L = (size_t)K->p.D + 1;
+  uint64_t* d_work; int64_t* d_tab; int32_t* d_idx = nullptr;
+  HIPCHK(hipMalloc(&d_work, count * L * 8));
+  HIPCHK(hipMalloc(&d_tab, ((size_t)ntab << w) * 8));
+  HIPCHK(hipMemcpy(d_work, cts, count * L * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_tab, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
+  if (table_idx) {
+    HIPCHK(hipMalloc(&d_idx, count * 4));
+    HIPCHK(hipMemcpy(d_idx, table_idx, count * 4, hipMemcpyHostToDevice));
+  }
+  LutScratch sc;
+  CHK(alloc_lut_scratch(K, std::min<size_t>(count, 4096), &sc));
+  if (r > 0) {
+    hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work, d_work, count, L, 0, 1ULL << (63 - p + r - 1));
+    HIPCHK(hipGetLastError());
+  }
+  CHK(dev_round_lut(K, bit_tier, tab_tier, d_work, count, p, r, d_tab, w, d_idx, 1, 1, sc, nullptr));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cts_out, d_work, count * L * 8, hipMemcpyDeviceToHost));
+  free_lut_scratch(&sc);
+  hipFree(d_work); hipFree(d_tab); if (d_idx) hipFree(d_idx);
+  return 0;
+}
+
+extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int batch, int Cin, int H, int W, const int8_t* weight, int Cout,
+                             int KH, int KW, int stride, int pad, uint64_t* out) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t L = (size_t)D + 1;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const size_t nin = (size_t)batch * Cin * H * W * L, nout = (size_t)batch * Cout * Ho * Wo * L, nw = (size_t)Cout * Cin * KH * KW;
+  uint64_t *d_in, *d_out; int8_t* d_w;
+  HIPCHK(hipMalloc(&d_in, nin * 8));
+  HIPCHK(hipMalloc(&d_out, nout * 8));
+  HIPCHK(hipMalloc(&d_w, nw));
+  HIPCHK(hipMemcpy(d_in, in, nin * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_w, weight, nw, hipMemcpyHostToDevice));
+  CHK(dev_conv2d(ctx->stream, d_in, batch, Cin, H, W, L, d_w, Cout, KH, KW, stride, pad, d_out));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d_out, nout * 8, hipMemcpyDeviceToHost));
+  hipFree(d_in); hipFree(d_out); hipFree(d_w);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ circuit
+struct BlobHeader { uint32_t magic, version; int32_t n_tensors, n_ops, input_tensor, output_tensor, max_bit_width, reserved; };
+
+extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t size, dctfhe_circuit** out) {
+  if (size < sizeof(BlobHeader)) return fail("circuit blob too short");
+  BlobHeader h;
+  memcpy(&h, blob, sizeof h);
+  if (h.magic != 0x46544344u /* 'DCTF' */ || h.version != 1) return fail("bad circuit blob magic/version");
+  const size_t need = sizeof h + (size_t)h.n_tensors * sizeof(TensorShape) + (size_t)h.n_ops * sizeof(Op);
+  if (h.n_tensors < 1 || h.n_ops < 0 || size < need) return fail("circuit blob truncated");
+  HIPCHK(hipSetDevice(ctx->device));
+  auto* c = new dctfhe_circuit;
+  c->ctx = ctx;
+  c->tensors.resize(h.n_tensors);
+  c->ops.resize(h.n_ops);
+  const char* p = (const char*)blob + sizeof h;
+  memcpy(c->tensors.data(), p, (size_t)h.n_tensors * sizeof(TensorShape));
+  p += (size_t)h.n_tensors * sizeof(TensorShape);
+  memcpy(c->ops.data(), p, (size_t)h.n_ops * sizeof(Op));
+  c->input_tensor = h.input_tensor; c->output_tensor = h.output_tensor; c->max_bit_width = h.max_bit_width;
+  c->d_payload.assign(h.n_ops, nullptr);
+  for (int i = 0; i < h.n_ops; i++) {
+    const Op& o = c->ops[i];
+    auto bad_t = [&](int t) { return t < 0 || t >= h.n_tensors; };
+    if (bad_t(o.src0) || bad_t(o.dst) || (o.type == OP_ADD && bad_t(o.src1))) { delete c; return fail("op %d: tensor id out of range", i); }
+    if (o.payload_len > 0) {
+      if (o.payload_off < 0 || (size_t)(o.payload_off + o.payload_len) > size) { delete c; return fail("op %d: payload out of range", i); }
+      HIPCHK(hipMalloc(&c->d_payload[i], (size_t)o.payload_len));
+      HIPCHK(hipMemcpy(c->d_payload[i], (const char*)blob + o.payload_off, (size_t)o.payload_len, hipMemcpyHostToDevice));
+    }
+  }
+  *out = c;
+  return 0;
+}
+extern "C" int dctfhe_circuit_destroy(dctfhe_circuit* c) {
+  if (!c) return 0;
+  hipSetDevice(c->ctx->device);
+  for (void* p : c->d_payload) if (p) hipFree(p);
+  delete c;
+  return 0;
+}
+extern "C" int dctfhe_circuit_io(dctfhe_circuit* c, int64_t* n_in, int64_t* n_out) {
+  const TensorShape& a = c->tensors[c->input_tensor];
+  const TensorShape& b = c->tensors[c->output_tensor];
+  *n_in = (int64_t)a.C * a.H * a.W;
+  *n_out = (int64_t)b.C * b.H * b.W;
+  return 0;
+}
+
+extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, dctfhe_stats* s) {
+  memset(s, 0, sizeof *s);
+  s->max_bit_width = c->max_bit_width;
+  s->n_ops = (int)c->ops.size();
+  const double Lb = (P->D + 1) * 8.0;
+  auto elems = [&](int t) { const TensorShape& x = c->tensors[t]; return (double)x.C * x.H * x.W; };
+  auto tier_flops = [&](const dctfhe_tier& t) {
+    const double N = (double)(1 << t.logN), M = N / 2;
+    const double fft = 5.0 * M * std::log2(M);
+    return t.n * ((t.k + 1) * t.l * fft + (t.k + 1) * fft + (double)(t.k + 1) * (t.k + 1) * t.l * M * 8.0);
+  };
+  auto key_bytes = [&](const dctfhe_tier& t) {
+    const double N = (double)(1 << t.logN);
+    return (double)t.n * t.l * (t.k + 1) * (t.k + 1) * N * 8.0 + (double)P->D * t.lk * (t.n + 1) * 8.0;
+  };
+  for (const Op& o : c->ops) {
+    const double ein = elems(o.src0), eout = elems(o.dst);
+    switch (o.type) {
+      case OP_CONV: {
+        const TensorShape& a = c->tensors[o.src0];
+        s->conv_macs += (int64_t)(eout * a.C * o.ip[1] * o.ip[2]);
+        s->bytes_algorithmic += (ein + eout) * Lb;
+        break;
+      }
+      case OP_ADD: s->bytes_algorithmic += 3 * eout * Lb; break;
+      case OP_SUMPOOL: s->bytes_algorithmic += (ein + eout) * Lb; break;
+      case OP_LUT: {
+        const int r = o.ip[1], tt = o.ip[4], bt = o.ip[5];
+        s->lut_sites += (int64_t)ein;
+        s->bit_steps += (int64_t)(ein * r);
+        s->bytes_algorithmic += 2 * ein * Lb * (1 + r);
+        if (tt >= 0 && tt < P->n_tiers) {
+          s->pbs_count[tt] += (int64_t)ein; s->ks_count[tt] += (int64_t)ein;
+          s->flops_f64 += ein * tier_flops(P->tiers[tt]);
+          s->key_bytes_per_pass += key_bytes(P->tiers[tt]);
+        }
+        if (r > 0 && bt >= 0 && bt < P->n_tiers) {
+          s->pbs_count[bt] += (int64_t)(ein * r); s->ks_count[bt] += (int64_t)(ein * r);
+          s->flops_f64 += ein * r * tier_flops(P->tiers[bt]);
+          s->key_bytes_per_pass += r * key_bytes(P->tiers[bt]);
+        }
+        break;
+      }
+      default: break;
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ session
+extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_keys* keys, int batch, dctfhe_session** out) {
+  if (batch < 1) return fail("batch must be >= 1");
+  HIPCHK(hipSetDevice(ctx->device));
+  auto* s = new dctfhe_session;
+  s->ctx = ctx; s->circ = circ; s->keys = keys; s->batch = batch;
+  s->D = keys ? keys->p.D : 0;
+  const size_t L = (size_t)s->D + 1;
+  // validate tiers named by the circuit
+  if (keys)
+    for (size_t i = 0; i < circ->ops.size(); i++) {
+      const Op& o = circ->ops[i];
+      if (o.type != OP_LUT) continue;
+      const int tt = o.ip[4], bt = o.ip[5], r = o.ip[1], w = o.ip[2];
+      if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) { delete s; return fail("op %zu names a tier the keys lack", i); }
+      if (w > keys->p.tiers[tt].logN - 1) { delete s; return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt); }
+    }
+  // tensor liveness: free a buffer after its last reader; reuse freed buffers of sufficient size
+  const int nt = (int)circ->tensors.size();
+  std::vector<int> last_use(nt, -1);
+  for (int i = 0; i < (int)circ->ops.size(); i++) {
+    const Op& o = circ->ops[i];
+    last_use[o.src0] = i;
+    if (o.type == OP_ADD) last_use[o.src1] = i;
+  }
+  last_use[circ->output_tensor] = 1 << 30;
+  s->d_tensor.assign(nt, nullptr);
+  s->tensor_words.assign(nt, 0);
+  for (int t = 0; t < nt; t++) {
+    const TensorShape& x = circ->tensors[t];
+    s->tensor_words[t] = (size_t)batch * x.C * x.H * x.W * L;
+  }
+  std::vector<std::pair<size_t, uint64_t*>> freelist;
+  auto get = [&](size_t words, uint64_t** p) -> int {
+    int best = -1;
+    for (int i = 0; i < (int)freelist.size(); i++)
+      if (freelist[i].first >= words && (best < 0 || freelist[i].first < freelist[best].first)) best = i;
+    if (best >= 0) { *p = freelist[best].second; freelist.erase(freelist.begin() + best); return 0; }
+    HIPCHK(hipMalloc(p, words * 8));
+    s->owned.push_back({words, *p});
+    return 0;
+  };
+  std::map<uint64_t*, size_t> cap;
+  auto alloc_t = [&](int t) -> int {
+    if (s->d_tensor[t]) return 0;
+    uint64_t* p = nullptr;
+    CHK(get(s->tensor_words[t], &p));
+    s->d_tensor[t] = p;
+    if (!cap.count(p)) cap[p] = s->tensor_words[t];
+    return 0;
+  };
+  if (alloc_t(circ->input_tensor)) { delete s; return -1; }
+  for (int i = 0; i < (int)circ->ops.size(); i++) {
+    const Op& o = circ->ops[i];
+    if (alloc_t(o.dst)) { delete s; return -1; }
+    auto release = [&](int t) {
+      if (last_use[t] == i && t != o.dst && s->d_tensor[t]) freelist.push_back({cap[s->d_tensor[t]], s->d_tensor[t]});
+    };
+    release(o.src0);
+    if (o.type == OP_ADD && o.src1 != o.src0) release(o.src1);
+  }
+  if (keys) {
+    size_t maxe = 1;
+    for (const Op& o : circ->ops)
+      if (o.type == OP_LUT) { const TensorShape& x = circ->tensors[o.src0]; maxe = std::max(maxe, (size_t)batch * x.C * x.H * x.W); }
+    LutScratch sc;
+    if (alloc_lut_scratch(keys, std::min<size_t>(maxe, 16384), &sc)) { delete s; return -1; }
+    s->chunk = sc.chunk; s->d_digits = sc.digits; s->d_bodies = sc.bodies; s->d_small = sc.small; s->d_bit_tables = sc.bit_tables;
+  }
+  HIPCHK(hipMalloc(&s->d_overflow, sizeof(int)));
+  HIPCHK(hipMemset(s->d_overflow, 0, sizeof(int)));
+  *out = s;
+  return 0;
+}
+
+extern "C" int dctfhe_session_destroy(dctfhe_session* s) {
+  if (!s) return 0;
+  hipSetDevice(s->ctx->device);
+  for (auto& o : s->owned) hipFree(o.second);
+  hipFree(s->d_digits); hipFree(s->d_bodies); hipFree(s->d_small); hipFree(s->d_bit_tables); hipFree(s->d_overflow);
+  delete s;
+  return 0;
+}
+
+extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) {
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const int t = s->circ->input_tensor;
+  HIPCHK(hipMemcpyAsync(s->d_tensor[t], cts_in, s->tensor_words[t] * 8, hipMemcpyHostToDevice, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return 0;
+}
+extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
+  HIPCHK(hipSetDevice(s->ctx->device));
+  const int t = s->circ->output_tensor;
+  HIPCHK(hipMemcpyAsync(cts_out, s->d_tensor[t], s->tensor_words[t] * 8, hipMemcpyDeviceToHost, s->ctx->stream));
+  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  return 0;
+}
+
+extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
+  HIPCHK(hipSetDevice(s->ctx->device));
+  hipStream_t st = s->ctx->stream;
+  dctfhe_circuit* c = s->circ;
+  dctfhe_keys* K = s->keys;
+  const size_t L = (size_t)s->D + 1;
+  const int B = s->batch;
+  Timers tm{st, timing != nullptr, {}};
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, st));
+  if (timing) memset(timing, 0, sizeof *timing);
+  LutScratch sc{s->d_digits, s->d_bodies, s->d_small, s->d_bit_tables, s->chunk};
+  for (size_t i = 0; i < c->ops.size(); i++) {
+    const Op& o = c->ops[i];
+    const TensorShape& a = c->tensors[o.src0];
+    const TensorShape& d = c->tensors[o.dst];
+    uint64_t* src = s->d_tensor[o.src0];
+    uint64_t* dst = s->d_tensor[o.dst];
+    switch (o.type) {
+      case OP_CONV: {
+        const int h = tm.begin(CAT_LINEAR);
+        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, L, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst));
+        tm.end(h);
+        break;
+      }
+      case OP_ADD: {
+        const int h = tm.begin(CAT_LINEAR);
+        hipLaunchKernelGGL(k_add, dim3(ew_grid(s->tensor_words[o.dst])), dim3(256), 0, st, src, s->d_tensor[o.src1], dst, s->tensor_words[o.dst]);
+        HIPCHK(hipGetLastError());
+        tm.end(h);
+        break;
+      }
+      case OP_SUMPOOL: {
+        const int h = tm.begin(CAT_LINEAR);
+        const size_t tw = s->tensor_words[o.dst];
+        hipLaunchKernelGGL(k_sum_pool, dim3(ew_grid(tw)), dim3(256), 0, st, src, a.C, a.H, a.W, L, o.ip[0], d.H, d.W, dst, tw);
+        HIPCHK(hipGetLastError());
+        tm.end(h);
+        break;
+      }
+      case OP_LUT: {
+        const int p = o.ip[0], r = o.ip[1], w = o.ip[2], shift = o.ip[3], tt = o.ip[4], bt = o.ip[5], nchan = o.ip[6];
+        const size_t E = (size_t)B * a.C * a.H * a.W;
+        const uint64_t body_add = (uint64_t)o.lp[0];
+        const int hw = a.H * a.W;
+        if (!K) {
+          hipLaunchKernelGGL(k_lut_clear, dim3(ew_grid(E)), dim3(256), 0, st, src, dst, E, shift, body_add, p, r, w, (const int64_t*)c->d_payload[i],
+                             hw, nchan, s->d_overflow);
+          HIPCHK(hipGetLastError());
+        } else {
+          const int h = tm.begin(CAT_LINEAR);
+          const uint64_t add = body_add + (r > 0 ? (1ULL << (63 - p + r - 1)) : 0);
+          hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * L)), dim3(256), 0, st, src, dst, E, L, shift, add);
+          HIPCHK(hipGetLastError());
+          tm.end(h);
+          CHK(dev_round_lut(K, bt, tt, dst, E, p, r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
+        }
+        break;
+      }
+      default: return fail("op %zu: unknown type %d", i, o.type);
+    }
+  }
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventSynchronize(e1));
+  if (timing) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    timing->total_ms = ms;
+    for (auto& sp : tm.spans) {
+      float t = 0;
+      hipEventElapsedTime(&t, sp.a, sp.b);
+      if (sp.cat == CAT_LINEAR) timing->linear_ms += t;
+      else if (sp.cat == CAT_KS) timing->ks_ms += t;
+      else if (sp.cat >= 0 && sp.cat < DCTFHE_MAX_TIERS) { timing->pbs_ms[sp.cat] += t; timing->pbs_launches[sp.cat]++; }
+      hipEventDestroy(sp.a); hipEventDestroy(sp.b);
+    }
+    if (K) {
+      dctfhe_stats stt;
+      dctfhe_circuit_stats(c, &K->p, &stt);
+      for (int i = 0; i < DCTFHE_MAX_TIERS; i++) timing->pbs_cts[i] = stt.pbs_count[i] * B;
+    }
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (!K) {
+    int ov = 0;
+    HIPCHK(hipMemcpy(&ov, s->d_overflow, sizeof ov, hipMemcpyDeviceToHost));
+    if (ov) { HIPCHK(hipMemset(s->d_overflow, 0, sizeof(int))); return fail("clear run: a message left its padded range (calibration too tight)"); }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ probes
+extern "C" int dctfhe_fp64_peak(dctfhe_ctx* ctx, double* tflops) {
+  HIPCHK(hipSetDevice(ctx->device));
+  const int blocks = ctx->prop.multiProcessorCount * 8, threads = 256, iters = 1 << 14;
+  double* d;
+  HIPCHK(hipMalloc(&d, (size_t)blocks * threads * 8));
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(k_fp64_peak, dim3(blocks), dim3(threads), 0, ctx->stream, d, iters);
+  hipEventRecord(a, ctx->stream);
+  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_fp64_peak, dim3(blocks), dim3(threads), 0, ctx->stream, d, iters);
+  hipEventRecord(b, ctx->stream);
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  *tflops = 4.0 * blocks * threads * (double)iters * 8 * 2 / (ms * 1e-3) / 1e12;
+  hipEventDestroy(a); hipEventDestroy(b);
+  hipFree(d);
+  return 0;
+}
+
+extern "C" int dctfhe_bench_pbs(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, size_t count, int reps, double* ms_per_launch) {
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const dctfhe_tier& t = K->p.tiers[tier];
+  const size_t L = (size_t)K->p.D + 1;
+  uint64_t *d_small, *d_out; int64_t* d_tab;
+  HIPCHK(hipMalloc(&d_small, count * (size_t)(t.n + 1) * 8));
+  HIPCHK(hipMalloc(&d_out, count * L * 8));
+  HIPCHK(hipMalloc(&d_tab, 8 * 16));
+  std::vector<uint64_t> h(count * (size_t)(t.n + 1));
+  uint64_t stt = 12345;
+  for (auto& v : h) { stt = stt * 6364136223846793005ULL + 1442695040888963407ULL; v = stt; }
+  HIPCHK(hipMemcpy(d_small, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  int64_t tab[16];
+  for (int i = 0; i < 16; i++) tab[i] = (int64_t)i << 58;
+  HIPCHK(hipMemcpy(d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  CHK(dev_pbs(K, tier, d_small, count, d_tab, 4, nullptr, 1, 1, 0, d_out, 0, 0, nullptr));
+  hipEventRecord(a, ctx->stream);
+  for (int r = 0; r < reps; r++) CHK(dev_pbs(K, tier, d_small, count, d_tab, 4, nullptr, 1, 1, 0, d_out, 0, 0, nullptr));
+  hipEventRecord(b, ctx->stream);
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  *ms_per_launch = ms / reps;
+  hipEventDestroy(a); hipEventDestroy(b);
+  hipFree(d_small); hipFree(d_out); hipFree(d_tab);
+  return 0;
+}

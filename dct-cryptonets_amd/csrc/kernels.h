@@ -1,0 +1,370 @@
+// kernels.h -- gfx950 kernels of the homomorphic-evaluation engine.
+//   K1 conv2d / K2 add, sum-pool, affine      ciphertext streaming, u64 wrap arithmetic (HBM bound)
+//   K3 key switch = decompose + integer GEMM  (ks_decompose, ks_gemm)
+//   K4+K5+K6 programmable bootstrap           (pbs_kernel: mod-switch, blind rotate, sample extract)
+//   K9 keygen / encrypt / decrypt             client side, off the timed path
+// Semantics: oracle/tfhe_ref.h (the CPU restatement these are checked against).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pbs_core.h"
+
+namespace dctfhe {
+
+// ------------------------------------------------------------------------------------------ rng
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+// counter-based: (seed, stream, index) -> 64 uniform bits
+__device__ __forceinline__ uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t idx) {
+  return mix64(mix64(seed ^ (stream * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)) + idx * 0xD1B54A32D192ED03ULL);
+}
+__device__ __forceinline__ int64_t gauss_torus(uint64_t seed, uint64_t stream, uint64_t idx, double sigma) {
+  if (sigma <= 0.0) return 0;
+  const double u1 = ((double)(rnd64(seed, stream, 2 * idx) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(rnd64(seed, stream, 2 * idx + 1) >> 11)) * (1.0 / 9007199254740992.0);
+  const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+  return (int64_t)rint(g * sigma * 18446744073709551616.0);
+}
+
+enum : uint64_t { STREAM_BIGKEY = 1, STREAM_SMALLKEY = 2, STREAM_KSK = 16, STREAM_BSK_MASK = 64, STREAM_BSK_NOISE = 128,
+                  STREAM_ENC = 256 };
+
+__global__ void k_gen_bits(uint64_t seed, uint64_t stream, uint8_t* out, int len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) out[i] = (uint8_t)(rnd64(seed, stream, (uint64_t)i) >> 63);
+}
+
+__device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  uint64_t s = 0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); i++) s += red[i];
+  return s;  // valid in thread 0
+}
+
+// ------------------------------------------------------------------------------------------ client
+// one block per ciphertext: a random on [0,dim_eff), b = <a,S> + phase + e
+__global__ void k_lwe_encrypt(const uint8_t* __restrict__ S, int D, int dim_eff, const uint64_t* __restrict__ phases,
+                              double sigma, uint64_t seed, uint64_t* __restrict__ cts) {
+  __shared__ uint64_t red[16];
+  const size_t c = blockIdx.x;
+  uint64_t* ct = cts + c * (size_t)(D + 1);
+  uint64_t part = 0;
+  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+    const uint64_t a = (j < dim_eff) ? rnd64(seed, STREAM_ENC, c * (uint64_t)(D + 1) + j) : 0;
+    ct[j] = a;
+    if (S[j]) part += a;
+  }
+  const uint64_t s = block_reduce_add(part, red);
+  if (threadIdx.x == 0) ct[D] = s + phases[c] + (uint64_t)gauss_torus(seed, STREAM_ENC + 1, c, sigma);
+}
+
+__global__ void k_lwe_phase(const uint8_t* __restrict__ S, int D, const uint64_t* __restrict__ cts, uint64_t* __restrict__ phases) {
+  __shared__ uint64_t red[16];
+  const size_t c = blockIdx.x;
+  const uint64_t* ct = cts + c * (size_t)(D + 1);
+  uint64_t part = 0;
+  for (int j = threadIdx.x; j < D; j += blockDim.x)
+    if (S[j]) part += ct[j];
+  const uint64_t s = block_reduce_add(part, red);
+  if (threadIdx.x == 0) phases[c] = ct[D] - s;
+}
+
+// ------------------------------------------------------------------------------------------ keygen
+// key-switch key: one block per row (i, lev): LWE_s(S_i * 2^(64 - betak (lev+1)))
+__global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restrict__ s, int n, int lk, int betak,
+                          double sigma, uint64_t seed, uint64_t stream, uint64_t* __restrict__ ksk) {
+  __shared__ uint64_t red[16];
+  const size_t row = blockIdx.x;
+  const int i = (int)(row / lk), lev = (int)(row % lk);
+  uint64_t* dst = ksk + row * (size_t)(n + 1);
+  uint64_t part = 0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const uint64_t a = rnd64(seed, stream, row * (uint64_t)(n + 1) + j);
+    dst[j] = a;
+    if (s[j]) part += a;
+  }
+  const uint64_t sum = block_reduce_add(part, red);
+  if (threadIdx.x == 0) {
+    uint64_t b = sum + (uint64_t)gauss_torus(seed, stream + 1, row, sigma);
+    if (S[i]) b += 1ULL << (64 - betak * (lev + 1));
+    dst[n] = b;
+  }
+}
+
+// bootstrap key, standard domain, rows [i0, i0+ni) x rows_per_bit: GLWE(0) + s_i * gadget.
+// One block per row; the mask polynomial is parked in LDS while the body accumulates A * S.
+__global__ void k_bsk_gen_std(const uint8_t* __restrict__ s_small, const uint8_t* __restrict__ S_glwe, int i0, int k, int N, int l,
+                              int beta, double sigma, uint64_t seed, uint64_t stream, uint64_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* A = reinterpret_cast<uint64_t*>(smem_raw);
+  const int rows = (k + 1) * l;
+  const int i = i0 + (int)(blockIdx.x / rows), r = (int)(blockIdx.x % rows);
+  const uint64_t grow = (uint64_t)i * rows + r;  // global row id: randomness does not depend on chunking
+  uint64_t* row = out + (size_t)blockIdx.x * (k + 1) * N;
+  uint64_t* B = row + (size_t)k * N;
+  for (int c = threadIdx.x; c < N; c += blockDim.x)
+    B[c] = (uint64_t)gauss_torus(seed, stream + 1, grow * (uint64_t)N + c, sigma);
+  for (int j = 0; j < k; j++) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+      const uint64_t a = rnd64(seed, stream, (grow * (uint64_t)k + j) * (uint64_t)N + c);
+      A[c] = a;
+      row[(size_t)j * N + c] = a;
+    }
+    __syncthreads();
+    const uint8_t* Sj = S_glwe + (size_t)j * N;
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+      uint64_t acc = 0;
+      for (int m = 0; m < N; m++) {
+        if (!Sj[m]) continue;  // uniform branch
+        const int src = c - m;
+        acc += (src >= 0) ? A[src] : (uint64_t)0 - A[src + N];
+      }
+      B[c] += acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_small[i]) {
+    const int p = r / l, lev = r % l;
+    row[(size_t)p * N] += 1ULL << (64 - beta * (lev + 1));
+  }
+}
+
+// standard-domain key polynomials -> Fourier device layout; GROUPS polynomials per block
+template <int LOGN, int P, int GROUPS>
+__global__ void __launch_bounds__((fft_geom<LOGN - 1, P>::T * GROUPS))
+k_bsk_fourier(const uint64_t* __restrict__ polys, size_t npoly, const cplx* __restrict__ tw_g, cplx* __restrict__ out) {
+  using F = fft_geom<LOGN - 1, P>;
+  constexpr int T = F::T, N = 1 << LOGN, M = N / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cplx* tw = reinterpret_cast<cplx*>(smem_raw);
+  cplx* exch_all = tw + F::TW_ELEMS;
+  for (int x = threadIdx.x; x < F::TW_ELEMS; x += blockDim.x) tw[x] = tw_g[x];
+  __syncthreads();
+  const int g = threadIdx.x / T, t = threadIdx.x % T;
+  size_t q = (size_t)blockIdx.x * GROUPS + g;
+  if (q >= npoly) q = npoly - 1;  // redundant work keeps every thread on the barriers
+  cplx* exch = exch_all + (size_t)g * F::EXCH_ELEMS;
+  key_poly_to_fourier<LOGN, P>(polys + q * N, out + q * M, t, tw, exch, [] { __syncthreads(); });
+}
+
+// ------------------------------------------------------------------------------------------ K3 key switch
+// Step 1: digits of (ct << shift) for every mask word, offset to unsigned: dig' = dig + B/2 in [0,B).
+// Layout digits[c][i*lk + lev] (u8).  Also copies the (shifted) body.
+__global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, int D, int shift, int lk, int betak,
+                               uint8_t* __restrict__ digits, uint64_t* __restrict__ bodies) {
+  const size_t total = count * (size_t)D;
+  const int half = 1 << (betak - 1);
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = x / D;
+    const int i = (int)(x % D);
+    const uint64_t v = cts[c * (size_t)(D + 1) + i] << shift;
+    const int tot = lk * betak;
+    uint64_t xx = (v + (1ULL << (63 - tot))) >> (64 - tot);
+    const uint64_t B = 1ULL << betak, mask = B - 1;
+    uint64_t carry = 0;
+    uint8_t* dst = digits + (c * (size_t)D + i) * lk;
+    for (int lev = lk - 1; lev >= 0; lev--) {
+      uint64_t d = (xx & mask) + carry;
+      xx >>= betak;
+      int dv;
+      if (d >= (uint64_t)half) { dv = (int)d - (int)B; carry = 1; } else { dv = (int)d; carry = 0; }
+      dst[lev] = (uint8_t)(dv + half);
+    }
+    if (i == 0) bodies[c] = cts[c * (size_t)(D + 1) + D] << shift;
+  }
+}
+
+// Step 2: out[c][j] = body_c*[j==n] - sum_r (dig'[c][r] - B/2) * ksk[r][j]
+//       = body_c*[j==n] + (B/2) * colsum[j] - sum_r dig'[c][r] * ksk[r][j],   colsum[j] = sum_r ksk[r][j].
+// Block: CT ciphertexts x 256 columns; digits are wave-uniform (scalar loads), the key is read
+// once per block -- coalesced 8 B per lane -- and reused for CT ciphertexts.
+template <int CT>
+__global__ void __launch_bounds__(256)
+k_ks_gemm(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R /* D*lk */,
+          const uint64_t* __restrict__ ksk, const uint64_t* __restrict__ colsum, int n, int betak,
+          uint64_t* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const size_t c0 = (size_t)blockIdx.y * CT;
+  const bool live = j <= n;
+  const int jj = live ? j : n;
+  uint64_t acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) acc[c] = 0;
+  const uint8_t* dbase = digits + c0 * (size_t)R;
+  for (int r = 0; r < R; r += 4) {
+    uint64_t kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) kv[u] = ksk[(size_t)(r + u) * (n + 1) + jj];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const size_t cc = (c0 + c < count) ? (size_t)c : 0;
+      const uint32_t d4 = *reinterpret_cast<const uint32_t*>(dbase + cc * (size_t)R + r);  // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[c] += (uint64_t)((d4 >> (8 * u)) & 0xFF) * kv[u];
+    }
+  }
+  if (!live) return;
+  const uint64_t fix = ((uint64_t)1 << (betak - 1)) * colsum[j];
+#pragma unroll
+  for (int c = 0; c < CT; c++) {
+    if (c0 + c >= count) break;
+    out[(c0 + c) * (size_t)(n + 1) + j] = (j == n ? bodies[c0 + c] : 0) + fix - acc[c];
+  }
+}
+
+__global__ void k_ksk_colsum(const uint64_t* __restrict__ ksk, int R, int n, uint64_t* __restrict__ colsum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  uint64_t s = 0;
+  for (int r = 0; r < R; r++) s += ksk[(size_t)r * (n + 1) + j];
+  colsum[j] = s;
+}
+
+// ------------------------------------------------------------------------------------------ K4-K6 bootstrap
+struct pbs_launch {
+  const uint64_t* cts_small;  // count x (n+1)
+  size_t count;
+  int n, beta;
+  const cplx* bsk;
+  const cplx* tw;             // twiddle table in global memory
+  const int64_t* tables;      // [ntab][2^w]
+  int w;
+  const int32_t* table_idx;   // optional explicit index per ciphertext
+  int hw, nchan;              // else table = ((e_offset + e) / hw) % nchan  (nchan == 1: single table)
+  size_t e_offset;
+  uint64_t* out;              // count x (D_out+1)
+  int D_out;
+  int accumulate;
+  uint64_t body_add;
+  uint64_t* dummy;            // D_out+1 words: sink for the padded groups of the last workgroup
+};
+
+template <int LOGN, int K, int L, int P, int GROUPS>
+__global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P>::T * GROUPS), 1)
+pbs_kernel(pbs_launch a) {
+  using G = pbs_geom<LOGN, K, L, P>;
+  constexpr int T = G::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  cplx* tw = reinterpret_cast<cplx*>(smem_raw);
+  unsigned char* per_group = smem_raw + G::TW_BYTES;
+  for (int x = threadIdx.x; x < G::F::TW_ELEMS; x += blockDim.x) tw[x] = a.tw[x];
+  __syncthreads();
+  const int g = threadIdx.x / T, t = threadIdx.x % T;
+  size_t e = (size_t)blockIdx.x * GROUPS + g;
+  const bool live = e < a.count;
+  if (!live) e = a.count - 1;  // padded groups redo the last ciphertext and drop the result
+  cplx* exch = reinterpret_cast<cplx*>(per_group + (size_t)g * (G::EXCH_BYTES + G::STAGE_BYTES));
+  uint64_t* stage = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(exch) + G::EXCH_BYTES);
+  pbs_args A;
+  A.ct_small = a.cts_small + e * (size_t)(a.n + 1);
+  A.n = a.n; A.beta = a.beta; A.bsk = a.bsk;
+  const size_t ti = a.table_idx ? (size_t)a.table_idx[e] : (a.nchan > 1 ? ((a.e_offset + e) / (size_t)a.hw) % (size_t)a.nchan : 0);
+  A.table = a.tables + (ti << a.w);
+  A.w = a.w;
+  // padded groups of the last workgroup redo the last ciphertext (same barrier sequence) into a sink
+  A.out = live ? a.out + e * (size_t)(a.D_out + 1) : a.dummy;
+  A.D_out = a.D_out;
+  A.accumulate = live ? a.accumulate : 0;
+  A.body_add = a.body_add;
+  pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, [] { __syncthreads(); });
+}
+
+// ------------------------------------------------------------------------------------------ K1 conv2d
+// out[b][co][y][x][word] = sum_{ci,ky,kx} w[co][ci][ky][kx] * in[b][ci][y*s+ky-p][x*s+kx-p][word]  (mod 2^64)
+// Thread = one ciphertext word of one output pixel for a tile of COT output channels; lanes run over
+// words, so every load is a coalesced stream of one input ciphertext.
+template <int COT>
+__global__ void __launch_bounds__(256)
+k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1 */, const int8_t* __restrict__ wgt, int Cout,
+         int KH, int KW, int stride, int pad, int Ho, int Wo, uint64_t* __restrict__ out) {
+  const size_t word = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int pix = blockIdx.y;           // b*Ho*Wo + y*Wo + x
+  const int co0 = blockIdx.z * COT;
+  const int b = pix / (Ho * Wo), y = (pix / Wo) % Ho, x = pix % Wo;
+  if (word >= L) return;
+  uint64_t acc[COT];
+#pragma unroll
+  for (int c = 0; c < COT; c++) acc[c] = 0;
+  const uint64_t* inb = in + (size_t)b * Cin * H * W * L;
+  for (int ci = 0; ci < Cin; ci++)
+    for (int ky = 0; ky < KH; ky++) {
+      const int iy = y * stride + ky - pad;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < KW; kx++) {
+        const int ix = x * stride + kx - pad;
+        if (ix < 0 || ix >= W) continue;
+        const uint64_t v = inb[(((size_t)ci * H + iy) * W + ix) * L + word];
+#pragma unroll
+        for (int c = 0; c < COT; c++) {
+          const int co = co0 + c;
+          const int8_t wv = (co < Cout) ? wgt[(((size_t)co * Cin + ci) * KH + ky) * KW + kx] : (int8_t)0;  // uniform
+          acc[c] += (uint64_t)(int64_t)wv * v;
+        }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < COT; c++) {
+    const int co = co0 + c;
+    if (co < Cout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * L + word] = acc[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ K2 elementwise
+__global__ void k_add(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ o, size_t nwords) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
+// o = (a << shift), body += body_add   (mask words only shifted)
+__global__ void k_affine(const uint64_t* __restrict__ a, uint64_t* __restrict__ o, size_t count, size_t L, int shift, uint64_t body_add) {
+  const size_t total = count * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    uint64_t v = a[i] << shift;
+    if (i % L == L - 1) v += body_add;
+    o[i] = v;
+  }
+}
+// window-K sum pooling with floor semantics (reference nn.AvgPool2d(k): backbone.py:276; scale folded into the next table)
+__global__ void k_sum_pool(const uint64_t* __restrict__ in, int C, int H, int W, size_t L, int K, int Ho, int Wo, uint64_t* __restrict__ out,
+                           size_t total_words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_words; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t word = i % L;
+    size_t e = i / L;
+    const int x = (int)(e % Wo); e /= Wo;
+    const int y = (int)(e % Ho); e /= Ho;  // e = b*C + c
+    uint64_t s = 0;
+    for (int ky = 0; ky < K; ky++)
+      for (int kx = 0; kx < K; kx++) s += in[((e * H + (size_t)(y * K + ky)) * W + (size_t)(x * K + kx)) * L + word];
+    out[i] = s;
+  }
+}
+
+// clear-mode table look-up on 1-word "ciphertexts" (D = 0): same arithmetic as round_lut without noise
+__global__ void k_lut_clear(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t count, int shift, uint64_t body_add,
+                            int p, int r, int w, const int64_t* __restrict__ tables, int hw, int nchan, int* __restrict__ overflow) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+    uint64_t v = (in[e] << shift) + body_add;
+    if (r > 0) v += 1ULL << (63 - p + r - 1);
+    if (v >> 63) atomicOr(overflow, 1);  // message left the padded range: an FHE run would wrap
+    const uint64_t idx = (v >> (63 - w)) & ((1ULL << w) - 1);
+    const size_t ti = nchan > 1 ? (e / (size_t)hw) % (size_t)nchan : 0;
+    out[e] = (uint64_t)tables[(ti << w) + idx];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ f64 peak probe
+__global__ void k_fp64_peak(double* out, int iters) {
+  double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const double m = 1.0000001, c = 1e-7;
+  for (int i = 0; i < iters; i++) {
+    a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
+    a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+}  // namespace dctfhe

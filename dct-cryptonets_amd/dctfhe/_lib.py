@@ -1,0 +1,103 @@
+"""ctypes binding of libdctfhe.so (include/dctfhe.h).
+
+The library is built in-tree by __graft_entry__.build() (hipcc --offload-arch=gfx950) and lives at
+dct-cryptonets_amd/libdctfhe.so.  There is no fallback: if the library is missing, or no HIP
+device is visible, every operation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libdctfhe.so")
+MAX_TIERS = 8
+
+
+class Tier(C.Structure):
+    _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("logN", C.c_int32), ("l", C.c_int32), ("beta", C.c_int32),
+                ("lk", C.c_int32), ("betak", C.c_int32), ("ksk_share", C.c_int32),
+                ("lwe_sigma", C.c_double), ("glwe_sigma", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("D", C.c_int32), ("n_max", C.c_int32), ("n_tiers", C.c_int32), ("reserved", C.c_int32),
+                ("input_sigma", C.c_double), ("tiers", Tier * MAX_TIERS)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("pbs_count", C.c_int64 * MAX_TIERS), ("ks_count", C.c_int64 * MAX_TIERS), ("conv_macs", C.c_int64),
+                ("lut_sites", C.c_int64), ("bit_steps", C.c_int64), ("bytes_algorithmic", C.c_double),
+                ("key_bytes_per_pass", C.c_double), ("flops_f64", C.c_double), ("max_bit_width", C.c_int32),
+                ("n_ops", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("pbs_ms", C.c_double * MAX_TIERS), ("ks_ms", C.c_double),
+                ("linear_ms", C.c_double), ("pbs_launches", C.c_int64 * MAX_TIERS), ("pbs_cts", C.c_int64 * MAX_TIERS)]
+
+
+EXPORTS = [
+    "dctfhe_last_error", "dctfhe_version", "dctfhe_ctx_create", "dctfhe_ctx_destroy", "dctfhe_ctx_set_stream",
+    "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_keys_destroy", "dctfhe_keys_export_secret",
+    "dctfhe_keys_export_ksk", "dctfhe_keys_export_bsk", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch",
+    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_circuit_load", "dctfhe_circuit_destroy",
+    "dctfhe_circuit_stats", "dctfhe_circuit_io", "dctfhe_session_create", "dctfhe_session_destroy",
+    "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
+]
+
+_lib = None
+
+
+class DctfheError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdctfhe.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DctfheError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); this engine has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_size_t
+    L.dctfhe_last_error.restype = C.c_char_p
+    L.dctfhe_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.dctfhe_ctx_destroy.argtypes = [vp]
+    L.dctfhe_ctx_set_stream.argtypes = [vp, vp]
+    L.dctfhe_ctx_synchronize.argtypes = [vp]
+    L.dctfhe_keygen.argtypes = [vp, C.POINTER(Params), u64, C.POINTER(vp)]
+    L.dctfhe_keys_destroy.argtypes = [vp]
+    L.dctfhe_keys_export_secret.argtypes = [vp, vp, vp]
+    L.dctfhe_keys_export_ksk.argtypes = [vp, i32, vp]
+    L.dctfhe_keys_export_bsk.argtypes = [vp, i32, vp]
+    L.dctfhe_encrypt.argtypes = [vp, vp, vp, sz, u64, vp]
+    L.dctfhe_decrypt.argtypes = [vp, vp, vp, sz, vp]
+    L.dctfhe_keyswitch.argtypes = [vp, vp, i32, vp, sz, i32, vp]
+    L.dctfhe_pbs.argtypes = [vp, vp, i32, vp, sz, vp, i32, i32, vp, vp]
+    L.dctfhe_round_lut.argtypes = [vp, vp, i32, i32, vp, sz, i32, i32, vp, i32, i32, vp, vp]
+    L.dctfhe_conv2d.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    L.dctfhe_circuit_load.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.dctfhe_circuit_destroy.argtypes = [vp]
+    L.dctfhe_circuit_stats.argtypes = [vp, C.POINTER(Params), C.POINTER(Stats)]
+    L.dctfhe_circuit_io.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.dctfhe_session_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
+    L.dctfhe_session_destroy.argtypes = [vp]
+    L.dctfhe_session_upload.argtypes = [vp, vp]
+    L.dctfhe_session_run.argtypes = [vp, C.POINTER(Timing)]
+    L.dctfhe_session_download.argtypes = [vp, vp]
+    L.dctfhe_fp64_peak.argtypes = [vp, C.POINTER(C.c_double)]
+    L.dctfhe_bench_pbs.argtypes = [vp, vp, i32, sz, i32, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DctfheError(load().dctfhe_last_error().decode())
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
