@@ -1,0 +1,442 @@
+"""Circuit compiler: float model + calibration batch -> integer circuit for the HIP engine.
+
+Stands in for what `compile_brevitas_qat_model(model.module.feature, calib_data, rounding_threshold_bits,
+n_bits, p_error, ...)` does inside Concrete-ML (reference call site homomorphic_eval.py:276-285): import the
+quantised graph, fuse every float sub-graph between two integer linear ops into a per-channel table, give
+each accumulator a bit-width from the calibration set, and round accumulators to `rounding_threshold_bits`
+before their table (exact method, homomorphic_eval.py:279).  Brevitas/Concrete-ML are not available, so
+the quantisers are restated here (per-tensor scales from the calibration batch; weights `bit_width`-bit
+narrow range as reference models/backbone.py:217-223; activations as :224-227) and the circuit this
+produces is the specification the engine and the oracle are both held to.
+
+Circuit semantics (all integers):
+  CONV / ADD / SUMPOOL   exact integer arithmetic on message values
+  LUT(p, r, w, signed)   idx = m + (2^(p-1) if signed else 0);  t = (idx + 2^(r-1) * [r>0]) >> r;  y = table[channel][t]
+Encodings: a tensor with exponent e holds  phase = value * 2^e  (mod 2^64); a LUT shifts its input up to
+e = 63 - p first, so that t sits in the top w+1 bits with the padding bit clear.
+"""
+import math
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import params as P
+
+OP_CONV, OP_ADD, OP_SUMPOOL, OP_LUT = 1, 2, 3, 4
+MAGIC = 0x46544344
+
+
+# ------------------------------------------------------------------------------------------ quantisers
+def weight_quant(w, bits):
+    """per-tensor, narrow range (reference backbone.py:217-223: Int8WeightPerTensorFloat, narrow_range=True)"""
+    qmax = 2 ** (bits - 1) - 1
+    s = float(np.abs(w).max()) / qmax
+    if s == 0.0:
+        s = 1.0
+    return np.clip(np.rint(w / s), -qmax, qmax).astype(np.int64), s
+
+
+def act_scale(x, signed, bits):
+    m = float(np.abs(x).max()) if signed else float(max(x.max(), 0.0))
+    if m == 0.0:
+        m = 1.0
+    return m / ((2 ** (bits - 1) - 1) if signed else (2 ** bits - 1))
+
+
+def act_quant(x, s, signed, bits):
+    lo, hi = (-(2 ** (bits - 1)), 2 ** (bits - 1) - 1) if signed else (0, 2 ** bits - 1)
+    return np.clip(np.rint(x / s), lo, hi).astype(np.int64)
+
+
+def conv_int(q, w, stride, pad):
+    """exact integer convolution (values stay far below 2^53, so float64 is exact)"""
+    out = F.conv2d(torch.from_numpy(q.astype(np.float64)), torch.from_numpy(w.astype(np.float64)), stride=stride, padding=pad)
+    return np.rint(out.numpy()).astype(np.int64)
+
+
+def _bn_apply(bn, x):
+    sh = (1, -1, 1, 1)
+    return bn.gamma.reshape(sh) * (x - bn.mean.reshape(sh)) / np.sqrt(bn.var.reshape(sh) + bn.eps) + bn.beta.reshape(sh)
+
+
+def _bn_calibrate(bn, x):
+    if bn.mean is None:
+        bn.mean = x.mean(axis=(0, 2, 3))
+        bn.var = x.var(axis=(0, 2, 3))
+
+
+# ------------------------------------------------------------------------------------------ circuit objects
+@dataclass
+class TensorInfo:
+    C: int
+    H: int
+    W: int
+    e: int = None            # encoding exponent
+    lo: int = 0
+    hi: int = 0              # guaranteed (tables) or calibrated (accumulators) value range
+    var: float = 0.0         # noise variance estimate (torus^2)
+
+
+@dataclass
+class OpInfo:
+    type: int
+    src0: int
+    src1: int
+    dst: int
+    ip: list = field(default_factory=lambda: [0] * 12)
+    lp: list = field(default_factory=lambda: [0, 0])
+    payload: np.ndarray = None
+    # LUT metadata
+    p: int = 0
+    r: int = 0
+    w: int = 0
+    signed: bool = False
+    table_values: np.ndarray = None   # [ntab, 2^w] integer outputs (before encoding)
+    nu2: float = 1.0
+    note: str = ""
+    pfail: float = 0.0
+
+
+@dataclass
+class CompiledCircuit:
+    tensors: list
+    ops: list
+    input_tensor: int
+    output_tensor: int
+    in_scale: float
+    in_bits: int
+    out_scale: float
+    out_bits: int
+    max_bit_width: int
+    param_set: object
+    rounding_threshold_bits: int
+    n_bits: int
+    blob: bytes = b""
+    expected_failures_per_image: float = 0.0
+
+    @property
+    def e_in(self):
+        return self.tensors[self.input_tensor].e
+
+    @property
+    def e_out(self):
+        return self.tensors[self.output_tensor].e
+
+    def n_in(self):
+        t = self.tensors[self.input_tensor]
+        return t.C * t.H * t.W
+
+    def n_out(self):
+        t = self.tensors[self.output_tensor]
+        return t.C * t.H * t.W
+
+    def report(self):
+        """Text dump standing in for `fhe_circuit.mlir` (reference homomorphic_eval.py:309-311)."""
+        names = {OP_CONV: "conv2d", OP_ADD: "add", OP_SUMPOOL: "sum_pool", OP_LUT: "round_lut"}
+        ps = self.param_set
+        lines = [f"// dctfhe circuit: {len(self.ops)} ops, max accumulator bit-width {self.max_bit_width}, D={ps.D}"]
+        for i, t in enumerate(ps.tiers):
+            lines.append(f"// tier {i} {t.name}: n={t.n} k={t.k} N={t.N} l={t.l} beta={t.beta} lk={t.lk} betak={t.betak} "
+                         f"sigma_lwe=2^{math.log2(t.lwe_sigma):.1f} sigma_glwe=2^{math.log2(t.glwe_sigma):.1f}")
+        for i, o in enumerate(self.ops):
+            s, d = self.tensors[o.src0], self.tensors[o.dst]
+            head = f"%{o.dst} = {names[o.type]}(%{o.src0}" + (f", %{o.src1}" if o.type == OP_ADD else "") + ")"
+            if o.type == OP_CONV:
+                head += f" {{cout={o.ip[0]}, k={o.ip[1]}x{o.ip[2]}, stride={o.ip[3]}, pad={o.ip[4]}, nu2={o.nu2:.0f}}}"
+            elif o.type == OP_SUMPOOL:
+                head += f" {{k={o.ip[0]}}}"
+            elif o.type == OP_LUT:
+                head += (f" {{p={o.p}, lsbs_removed={o.r}, table_bits={o.w}, signed={int(o.signed)}, shift={o.ip[3]}, "
+                         f"tier={ps.tiers[o.ip[4]].name}" + (f", bit_tier={ps.tiers[o.ip[5]].name}" if o.r else "") +
+                         f", tables={o.ip[6]}, p_fail/elt={o.pfail:.1e}}}  // {o.note}")
+            lines.append(f"{head} : [{s.C}x{s.H}x{s.W}] -> [{d.C}x{d.H}x{d.W}] e={d.e}")
+        lines.append(f"// expected table failures per image (noise model): {self.expected_failures_per_image:.2e}")
+        return "\n".join(lines)
+
+
+class _Act:
+    """integer activation during compilation: calibration values, scale, circuit tensor id, guaranteed range"""
+
+    def __init__(self, q, scale, tid, lo, hi):
+        self.q, self.scale, self.tid, self.lo, self.hi = q, scale, tid, lo, hi
+
+
+def _acc_precision(lo, hi, rtb, margin):
+    """smallest (p, r, signed) whose padded range holds [lo, hi] (widened by margin) after rounding"""
+    lo = int(math.floor(lo * (1 + margin))) if lo < 0 else int(lo)
+    hi = int(math.ceil(hi * (1 + margin)))
+    signed = lo < 0
+    for p in range(1, 40):
+        r = max(0, p - rtb)
+        half = (1 << (r - 1)) if r > 0 else 0
+        if signed:
+            ok = -(1 << (p - 1)) <= lo and hi + half <= (1 << (p - 1)) - 1
+        else:
+            ok = hi + half <= (1 << p) - 1
+        if ok:
+            return p, r, signed
+    raise ValueError("accumulator range too wide")
+
+
+def lut_index(m, p, r, signed):
+    idx = m + ((1 << (p - 1)) if signed else 0)
+    if r > 0:
+        idx = (idx + (1 << (r - 1))) >> r
+    return idx
+
+
+def lut_centers(p, r, w, signed):
+    """accumulator value each table entry stands for"""
+    return (np.arange(1 << w, dtype=np.int64) << r) - ((1 << (p - 1)) if signed else 0)
+
+
+class _Builder:
+    def __init__(self, ps, rtb, margin):
+        self.ps, self.rtb, self.margin = ps, rtb, margin
+        self.tensors, self.ops = [], []
+        self.max_bits = 0
+
+    def tensor(self, C, H, W, lo, hi):
+        self.tensors.append(TensorInfo(C, H, W, None, lo, hi))
+        return len(self.tensors) - 1
+
+    def conv(self, a, layer, bits):
+        wq, sw = weight_quant(layer.weight, bits)
+        acc = conv_int(a.q, wq, layer.stride, layer.pad)
+        Cout, _, KH, KW = wq.shape
+        tid = self.tensor(Cout, acc.shape[2], acc.shape[3], int(acc.min()), int(acc.max()))
+        op = OpInfo(OP_CONV, a.tid, -1, tid)
+        op.ip[:5] = [Cout, KH, KW, layer.stride, layer.pad]
+        op.payload = wq.astype(np.int8)
+        op.nu2 = float((wq.astype(np.float64) ** 2).sum(axis=(1, 2, 3)).max())
+        self.ops.append(op)
+        return _Act(acc, a.scale * sw, tid, int(acc.min()), int(acc.max()))
+
+    def add(self, a, b):
+        q = a.q + b.q
+        tid = self.tensor(*q.shape[1:], a.lo + b.lo, a.hi + b.hi)
+        self.ops.append(OpInfo(OP_ADD, a.tid, b.tid, tid))
+        return _Act(q, a.scale, tid, a.lo + b.lo, a.hi + b.hi)
+
+    def sum_pool(self, a, K):
+        B, C, H, W = a.q.shape
+        Ho, Wo = H // K, W // K     # floor mode drops the border (reference backbone.py:276 nn.AvgPool2d)
+        q = a.q[:, :, :Ho * K, :Wo * K].reshape(B, C, Ho, K, Wo, K).sum(axis=(3, 5))
+        tid = self.tensor(C, Ho, Wo, a.lo * K * K, a.hi * K * K)
+        op = OpInfo(OP_SUMPOOL, a.tid, -1, tid)
+        op.ip[0] = K
+        self.ops.append(op)
+        return _Act(q, a.scale, tid, a.lo * K * K, a.hi * K * K)
+
+    def lut(self, a, fn, per_channel, rounding, out_scale, note):
+        """fn(values[ntab or 1, n]) -> integer outputs; values are message values of `a` (ints).
+        rounding=True: `a` is an accumulator, calibrated range + rounding to rtb bits;
+        rounding=False: `a` has a guaranteed range, table covers it exactly."""
+        C = a.q.shape[1]
+        if rounding:
+            p, r, signed = _acc_precision(int(a.q.min()), int(a.q.max()), self.rtb, self.margin)
+        else:
+            p, r, signed = _acc_precision(a.lo, a.hi, 64, 0.0)
+        w = p - r
+        self.max_bits = max(self.max_bits, p)
+        centers = lut_centers(p, r, w, signed)
+        ntab = C if per_channel else 1
+        vals = np.broadcast_to(centers[None, :], (ntab, centers.size))
+        table = np.asarray(fn(vals), dtype=np.int64).reshape(ntab, 1 << w)
+        idx = lut_index(a.q, p, r, signed)
+        if idx.min() < 0 or idx.max() >= (1 << w):
+            raise ValueError(f"{note}: calibration values leave the table range")
+        ch = np.arange(C).reshape(1, C, 1, 1) if per_channel else np.zeros((1, 1, 1, 1), np.int64)
+        q = table[np.broadcast_to(ch, idx.shape), idx]
+        lo, hi = int(table.min()), int(table.max())
+        tid = self.tensor(*a.q.shape[1:], lo, hi)
+        op = OpInfo(OP_LUT, a.tid, -1, tid, p=p, r=r, w=w, signed=signed, table_values=table, note=note)
+        self.ops.append(op)
+        return _Act(q, out_scale, tid, lo, hi)
+
+
+def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=None, range_margin=0.05, p_error=None):
+    """-> CompiledCircuit.  calib: float [B, C, H, W] calibration inputs (reference: first training batch,
+    homomorphic_eval.py:258-261).  p_error is accepted for signature parity (homomorphic_eval.py:282); the
+    catalogue in dctfhe/params.py is exact-evaluation grade and its failure estimate is reported instead."""
+    ps = param_set or P.default_params()
+    calib = np.asarray(calib, dtype=np.float64)
+    bits = model.bit_width
+    bld = _Builder(ps, rounding_threshold_bits, range_margin)
+    sgn_lo, sgn_hi = -(2 ** (bits - 1)), 2 ** (bits - 1) - 1
+    uq_hi = 2 ** bits - 1
+
+    # quant_inp (client side, in the clear; reference backbone.py:231,241)
+    s_in = act_scale(calib, True, bits)
+    q0 = act_quant(calib, s_in, True, bits)
+    t_in = bld.tensor(*q0.shape[1:], sgn_lo, sgn_hi)
+    a = _Act(q0, s_in, t_in, sgn_lo, sgn_hi)
+
+    # stem: conv1 -> bn1 -> [QuantReLU] -> quant_out  (backbone.py:232-261), one fused per-channel table
+    acc = bld.conv(a, model.conv1, bits)
+    real = acc.q * acc.scale
+    _bn_calibrate(model.bn1, real)
+    h = _bn_apply(model.bn1, real)
+    if model.relu1:
+        s_r = act_scale(np.maximum(h, 0), False, bits)
+        hq = act_quant(np.maximum(h, 0), s_r, False, bits) * s_r
+    else:
+        s_r, hq = None, h
+    s_q0 = act_scale(hq, True, bits)
+
+    def chan_fn(bn, s_acc, post):
+        def fn(vals):
+            x = _bn_apply(bn, (vals * s_acc)[None, :, :, None])   # vals [C, n] -> [1, C, n, 1]
+            return post(x)[0, :, :, 0]
+        return fn
+
+    def stem_post(x):
+        if s_r is not None:
+            x = act_quant(np.maximum(x, 0), s_r, False, bits) * s_r
+        return act_quant(x, s_q0, True, bits)
+
+    a = bld.lut(acc, chan_fn(model.bn1, acc.scale, stem_post), True, True, s_q0, "stem: bn1+relu+quant_out")
+
+    for bi, blk in enumerate(model.blocks):
+        # C1 -> BN1 -> relu1 (u4)                                            backbone.py:94-96
+        acc1 = bld.conv(a, blk.C1, bits)
+        real1 = acc1.q * acc1.scale
+        _bn_calibrate(blk.BN1, real1)
+        h1 = np.maximum(_bn_apply(blk.BN1, real1), 0)
+        s_r1 = act_scale(h1, False, bits)
+        r1 = bld.lut(acc1, chan_fn(blk.BN1, acc1.scale, lambda x, s=s_r1: act_quant(np.maximum(x, 0), s, False, bits)), True, True, s_r1,
+                     f"block{bi}: BN1+relu1")
+        # C2 -> BN2 -> quant_out (s4)                                        backbone.py:97-99
+        acc2 = bld.conv(r1, blk.C2, bits)
+        real2 = acc2.q * acc2.scale
+        _bn_calibrate(blk.BN2, real2)
+        g2 = _bn_apply(blk.BN2, real2)
+        s_qo = act_scale(g2, True, bits)
+        main_hi, main_lo = sgn_hi * s_qo, sgn_lo * s_qo
+        # shortcut                                                           backbone.py:100
+        if blk.shortcut is None:
+            sc_lo, sc_hi = a.lo * a.scale, a.hi * a.scale
+            accs = None
+        else:
+            accs = bld.conv(a, blk.shortcut, bits)
+            reals = accs.q * accs.scale
+            _bn_calibrate(blk.BNshortcut, reals)
+            gs = _bn_apply(blk.BNshortcut, reals)
+            s_qs = act_scale(gs, True, bits)
+            sc_lo, sc_hi = sgn_lo * s_qs, sgn_hi * s_qs
+        # common integer scale of the residual sum: n_bits signed, guaranteed by construction
+        zmax, zmin = 2 ** (n_bits - 1) - 1, -(2 ** (n_bits - 1))
+        s_c = max(main_hi + sc_hi, -(main_lo + sc_lo)) / zmax
+        while (np.rint(main_hi / s_c) + np.rint(sc_hi / s_c) > zmax) or (np.rint(main_lo / s_c) + np.rint(sc_lo / s_c) < zmin):
+            s_c *= 1.01
+        u = bld.lut(acc2, chan_fn(blk.BN2, acc2.scale, lambda x, s=s_qo, c=s_c: np.rint(act_quant(x, s, True, bits) * s / c).astype(np.int64)),
+                    True, True, s_c, f"block{bi}: BN2+quant_out+rescale")
+        if accs is None:
+            v = bld.lut(a, lambda vals, s=a.scale, c=s_c: np.rint(vals * s / c).astype(np.int64), False, False, s_c, f"block{bi}: rescale shortcut")
+        else:
+            v = bld.lut(accs, chan_fn(blk.BNshortcut, accs.scale, lambda x, s=s_qs, c=s_c: np.rint(act_quant(x, s, True, bits) * s / c).astype(np.int64)),
+                        True, True, s_c, f"block{bi}: BNshortcut+BNquant_out+rescale")
+        z = bld.add(u, v)                                                    # backbone.py:102
+        zr = np.maximum(z.q * s_c, 0)
+        s_r2 = act_scale(zr, False, bits)
+        a = bld.lut(z, lambda vals, c=s_c, s=s_r2: act_quant(np.maximum(vals * c, 0), s, False, bits), False, False, s_r2, f"block{bi}: relu2")
+
+    # AvgPool2d(k) as a window sum, then QuantIdentity (s4)                  backbone.py:276-278
+    K = model.avgpool_kernel
+    pooled = bld.sum_pool(a, K)
+    realp = pooled.q * pooled.scale / (K * K)
+    s_f = act_scale(realp, True, bits)
+    out = bld.lut(pooled, lambda vals, s=pooled.scale / (K * K), f=s_f: act_quant(vals * s, f, True, bits), False, True, s_f, "avgpool+QuantIdentity")
+
+    circ = CompiledCircuit(tensors=bld.tensors, ops=bld.ops, input_tensor=t_in, output_tensor=out.tid, in_scale=s_in, in_bits=bits,
+                           out_scale=s_f, out_bits=bits, max_bit_width=bld.max_bits, param_set=ps,
+                           rounding_threshold_bits=rounding_threshold_bits, n_bits=n_bits)
+    _assign_encodings(circ)
+    _estimate_noise(circ)
+    circ.blob = _serialize(circ)
+    return circ
+
+
+# ------------------------------------------------------------------------------------------ encodings
+def _assign_encodings(circ):
+    T, ops = circ.tensors, circ.ops
+    req = [None] * len(T)
+    req[circ.output_tensor] = 63 - (circ.out_bits + 1)          # signed out_bits value + padding
+    for o in reversed(ops):
+        if o.type == OP_LUT:
+            need = 63 - o.p
+        else:
+            need = req[o.dst]
+        for s in ([o.src0, o.src1] if o.type == OP_ADD else [o.src0]):
+            req[s] = need if req[s] is None else min(req[s], need)
+    T[circ.input_tensor].e = req[circ.input_tensor]
+    for o in ops:
+        if o.type == OP_LUT:
+            T[o.dst].e = req[o.dst]
+            shift = (63 - o.p) - T[o.src0].e
+            assert shift >= 0
+            ps = circ.param_set
+            tier = ps.tier_for_width(o.w)
+            if o.w > ps.tiers[tier].logN - 1:
+                raise ValueError("table wider than the ring")
+            o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]
+            o.lp[0] = (1 << 62) if o.signed else 0
+            enc = (o.table_values.astype(object) * (1 << T[o.dst].e)) % (1 << 64)
+            o.payload = np.array(enc, dtype=np.uint64).view(np.int64)
+        else:
+            T[o.dst].e = T[o.src0].e
+            if o.type == OP_ADD:
+                assert T[o.src1].e == T[o.src0].e, "residual operands must share an encoding"
+
+
+# ------------------------------------------------------------------------------------------ noise budget
+def _estimate_noise(circ):
+    ps, T = circ.param_set, circ.tensors
+    T[circ.input_tensor].var = ps.input_sigma ** 2
+    total = 0.0
+    for o in circ.ops:
+        s = T[o.src0]
+        n_elt = s.C * s.H * s.W
+        if o.type == OP_CONV:
+            T[o.dst].var = o.nu2 * s.var
+        elif o.type == OP_ADD:
+            T[o.dst].var = s.var + T[o.src1].var
+        elif o.type == OP_SUMPOOL:
+            T[o.dst].var = o.ip[0] ** 2 * s.var
+        else:
+            tt = ps.tiers[o.ip[4]]
+            v_in = s.var * 4.0 ** o.ip[3]
+            pf = 0.0
+            if o.r > 0:
+                bt = ps.tiers[o.ip[5]]
+                vb = P.var_pbs_out(bt, ps.fft_noise_c)
+                for i in range(o.r):
+                    v = 4.0 ** (o.p - i) * (v_in + i * vb) + P.var_keyswitch(ps.D, bt) + P.var_modswitch(bt)
+                    pf += P.p_fail(0.25, v)
+                v_in = v_in + o.r * vb
+            v = v_in + P.var_keyswitch(ps.D, tt) + P.var_modswitch(tt)
+            pf += P.p_fail(2.0 ** -(o.w + 2), v)
+            o.pfail = pf
+            total += pf * n_elt
+            T[o.dst].var = P.var_pbs_out(tt, ps.fft_noise_c)
+    circ.expected_failures_per_image = total
+
+
+# ------------------------------------------------------------------------------------------ blob
+def _serialize(circ):
+    nT, nO = len(circ.tensors), len(circ.ops)
+    head = struct.pack("<IIiiiiii", MAGIC, 1, nT, nO, circ.input_tensor, circ.output_tensor, circ.max_bit_width, 0)
+    tens = b"".join(struct.pack("<iiii", t.C, t.H, t.W, 0) for t in circ.tensors)
+    off = len(head) + len(tens) + nO * 96
+    payloads, recs = [], []
+    for o in circ.ops:
+        pl = b"" if o.payload is None else np.ascontiguousarray(o.payload).tobytes()
+        pad = (-len(pl)) % 16
+        recs.append(struct.pack("<iiii12i2qqq", o.type, o.src0, max(o.src1, 0), o.dst, *[int(x) for x in o.ip],
+                                *[int(x) - (1 << 64) if int(x) >= (1 << 63) else int(x) for x in o.lp], off if pl else 0, len(pl)))
+        payloads.append(pl + b"\0" * pad)
+        off += len(pl) + pad
+    return head + tens + b"".join(recs) + b"".join(payloads)

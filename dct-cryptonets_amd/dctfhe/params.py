@@ -1,0 +1,127 @@
+"""Parameter tiers and the noise model that justifies them.
+
+The reference hands `p_error` to Concrete's optimizer (homomorphic_eval.py:282, run_homomorphic_eval.sh:26)
+and never sees the parameters it picks.  This build owns them: a static catalogue of tiers plus the
+textbook TFHE variance formulas (Chillotti et al. 2020, section 4; all variances in torus^2 units),
+used by the compiler to price every table site and to refuse a circuit whose failure budget is blown.
+
+Security: binary keys; the minimal noise for ~128-bit security is taken from the linear fit
+    log2 sigma_min(d) = -0.02641 * d + 2.49          (floor 2^-62)
+through the tfhe-rs 128-bit parameter sets (d = 742, 864, 2048) -- background knowledge, not a
+security proof; the catalogue never goes below it.
+"""
+import math
+from dataclasses import dataclass, field, asdict
+
+
+def sigma_min(d):
+    return 2.0 ** max(-62.0, -0.02641 * d + 2.49)
+
+
+@dataclass
+class TierSpec:
+    name: str
+    n: int
+    k: int
+    logN: int
+    l: int
+    beta: int
+    lk: int
+    betak: int
+    ksk_share: int = -1
+    lwe_sigma: float = 0.0
+    glwe_sigma: float = 0.0
+
+    def __post_init__(self):
+        if self.lwe_sigma == 0.0:
+            self.lwe_sigma = sigma_min(self.n)
+        if self.glwe_sigma == 0.0:
+            self.glwe_sigma = sigma_min(self.k << self.logN)
+
+    @property
+    def N(self):
+        return 1 << self.logN
+
+    def as_dict(self):
+        d = asdict(self)
+        d.pop("name")
+        return d
+
+
+@dataclass
+class ParamSet:
+    """D: big LWE dimension (master key); tiers by role."""
+    D: int
+    tiers: list
+    bit_tier: int                      # index of the one-bit (rounding) tier
+    table_tier_for_w: dict             # table input width w -> tier index
+    input_sigma: float = 0.0
+    fft_noise_c: float = 4.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
+
+    def __post_init__(self):
+        if self.input_sigma == 0.0:
+            self.input_sigma = sigma_min(self.D)
+
+    @property
+    def n_max(self):
+        return max(t.n for t in self.tiers)
+
+    def tier_for_width(self, w):
+        for ww in sorted(self.table_tier_for_w):
+            if w <= ww:
+                return self.table_tier_for_w[ww]
+        raise ValueError(f"no tier for a table of {w} input bits")
+
+
+# ------------------------------------------------------------------------------------------ variances
+def var_keyswitch(D_eff, t):
+    B = 2.0 ** t.betak
+    return D_eff * t.lk * ((B * B + 2) / 12.0) * t.lwe_sigma ** 2 + (D_eff / 2.0) * 2.0 ** (-2 * t.betak * t.lk) / 12.0
+
+
+def var_modswitch(t):
+    return (t.n / 2.0 + 1.0) / (48.0 * t.N ** 2)
+
+
+def var_pbs_out(t, fft_c=4.0):
+    B = 2.0 ** t.beta
+    kN = t.k * t.N
+    ext = t.l * (t.k + 1) * t.N * ((B * B + 2) / 12.0) * t.glwe_sigma ** 2 + (kN / 2.0 + 1.0) * 2.0 ** (-2 * t.beta * t.l) / 12.0
+    # f64 FFT rounding: key spectrum ~ sqrt(N) * 2^64/sqrt(12) carries 2^-53 relative error, times the digit
+    # spectrum ~ sqrt(N) * B/sqrt(12), averaged back by the inverse transform (/ sqrt(N/2)); in torus units:
+    fft = fft_c * 2.0 * (t.k + 1) * t.l * t.N * (B * B / 144.0) * 2.0 ** -106
+    return t.n * (ext + fft)
+
+
+def p_fail(margin, var):
+    """two-sided Gaussian tail beyond `margin`"""
+    if var <= 0:
+        return 0.0
+    return math.erfc(margin / math.sqrt(2.0 * var))
+
+
+# ------------------------------------------------------------------------------------------ catalogue
+def default_params():
+    """Exact-evaluation set: every table site fails with probability <~1e-10 under the model above.
+
+    T6 (6-bit tables after a rounded accumulator) needs N = 8192: its mod-switch noise must stay 6.4
+    sigma inside a 2^-8 half-box.  T5/T4 serve the 5-bit residual-sum tables and the 4-bit rescale
+    tables.  B is the one-bit tier of the rounding chain: margin 1/4, so a small ring, but two levels
+    because its output is subtracted from a p-bit accumulator."""
+    t6 = TierSpec("T6", n=864, k=1, logN=13, l=2, beta=17, lk=6, betak=3)
+    t5 = TierSpec("T5", n=864, k=1, logN=12, l=2, beta=16, lk=6, betak=3, ksk_share=0)
+    t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0)
+    b = TierSpec("B", n=660, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
+    return ParamSet(D=8192, tiers=[t6, t5, t4, b], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0})
+
+
+def test_params():
+    """Tiny rings for CPU-oracle-sized parity tests (NOT secure: dimensions far below the curve)."""
+    t_tab = TierSpec("t", n=48, k=1, logN=10, l=2, beta=12, lk=5, betak=4, lwe_sigma=2.0 ** -26, glwe_sigma=2.0 ** -48)
+    t_bit = TierSpec("b", n=40, k=2, logN=8, l=2, beta=10, lk=5, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -48)
+    return ParamSet(D=1024, tiers=[t_tab, t_bit], bit_tier=1, table_tier_for_w={6: 0}, input_sigma=2.0 ** -55)
+
+
+def to_c_params(ps):
+    from .engine import make_params
+    return make_params(ps.D, ps.n_max, [t.as_dict() for t in ps.tiers], ps.input_sigma)

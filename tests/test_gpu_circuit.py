@@ -1,0 +1,53 @@
+"""P1: decrypt(run(encrypt(q))) == noise-free integer circuit, element for element.
+Small model + small (insecure) rings so the whole thing also fits the CPU oracle; the full-size
+ResNet-20 run lives in tests/test_gpu_resnet20.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from dctfhe import models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    qm = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits=6, param_set=P.test_params())
+    yield qm, calib
+    qm.close()
+
+
+def _oracle_out(qm, q):
+    from oracle import circuit_ref
+    out, ov = circuit_ref.run_clear(qm.compiled.blob, qm.encode_input(q))
+    assert not ov
+    return qm.decode_output(out)
+
+
+def test_clear_mode_matches_oracle(tiny):
+    qm, calib = tiny
+    q = qm.quantize_input(calib[:8])
+    assert np.array_equal(qm.forward_quantized(q, "disable"), _oracle_out(qm, q))
+
+
+def test_execute_matches_integer_circuit(tiny):
+    qm, calib = tiny
+    qm.fhe_circuit.keygen(seed=5)
+    q = qm.quantize_input(calib[:6])
+    want = _oracle_out(qm, q)
+    got = qm.forward_quantized(q, "execute")
+    assert got.shape == want.shape == (6, qm.compiled.n_out())
+    assert np.array_equal(got, want)
+    # the float surface: forward() == dequantised integers
+    assert np.allclose(qm.forward(calib[:6], fhe="execute"), want * qm.compiled.out_scale)
+    assert qm.fhe_circuit.graph.maximum_integer_bit_width() <= 16
+    assert "round_lut" in qm.fhe_circuit.mlir
+
+
+def test_ragged_batches(tiny):
+    """batch sizes that do not fill the last workgroup / chunk"""
+    qm, calib = tiny
+    for B in (1, 3):
+        q = qm.quantize_input(calib[10:10 + B])
+        assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
