@@ -1,0 +1,181 @@
+"""Plaintext client-side front-end: image -> DCT-packed tensor.
+
+Restates the evaluation branch of the reference transform pipeline (reference data/datamgr.py:192-219):
+  Resize(int(filter*S*1.15)) -> CenterCrop(filter*S) -> GetDCT(filter) -> UpScaleDCT(S) -> ToTensorDCT
+  -> SubsetDCT -> Aggregate -> NormalizeDCT -> x[0]
+Pinned by goldens captured from the reference's own functions (tests/golden/frontend_golden.npz,
+tools/make_goldens.py): matrix2dct, SubsetDCT, Aggregate, NormalizeDCT and the statistics table.
+NOT pinned (OpenCV is absent): the 8-bit YCrCb conversion and the bilinear resizes; they
+follow OpenCV's documented arithmetic and are covered by self-consistency tests only.
+The whole front-end runs before quantise+encrypt (the reference does it inside the Dataset), so it
+never touches ciphertexts.
+"""
+import math
+import os
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "dct_stats.npz")
+
+# reference data/cvtransforms.py:1601-1613 (filter 4) and :1643-1683 (default pattern): kept low-frequency indices
+SUBSET_FILTER4 = {
+    24: ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13], [0, 1, 2, 4, 5, 8], [0, 1, 2, 4, 5, 8]),
+    48: (list(range(16)), list(range(16)), list(range(16))),
+}
+SUBSET_DEFAULT = {
+    6: ([0, 1, 4, 5], [0], [0]),
+    12: ([0, 1, 2, 8, 9, 10, 16, 17], [0, 8], [0, 8]),
+    24: ([0, 1, 2, 3, 4, 5, 8, 9, 10, 16, 17, 18, 24, 32], [0, 1, 3, 8, 24], [0, 1, 3, 8, 24]),
+    48: ([0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28, 29, 32, 33, 34, 35, 40, 41, 42, 43],
+         [0, 1, 2, 8, 9, 10, 16, 17], [0, 1, 2, 8, 9, 10, 16, 17]),
+}
+
+
+def load_stats():
+    z = np.load(_DATA)
+    return z["mean"], z["std"]
+
+
+# ------------------------------------------------------------------------------------------ pinned by goldens
+def matrix2dct(plane, size):
+    """(pixel - 128) blockwise orthonormal DCT-II, T B T^t per size x size block, flattened row-major;
+    trailing rows/cols that do not fill a block are dropped (reference cvfunctional.py:37-57)."""
+    m = plane.astype(np.int16).astype(np.float64) - 128.0
+    T = np.zeros((size, size))
+    for i in range(size):
+        for j in range(size):
+            T[i, j] = 1.0 / math.sqrt(size) if i == 0 else math.sqrt(2.0 / size) * math.cos((2 * j + 1) * i * math.pi / (2 * size))
+    bh, bw = m.shape[0] // size, m.shape[1] // size
+    blocks = m[:bh * size, :bw * size].reshape(bh, size, bw, size).transpose(0, 2, 1, 3)    # [bh, bw, s, s]
+    out = np.matmul(np.matmul(T, blocks), T.T)
+    return out.reshape(bh, bw, size * size)
+
+
+def subset_indices(channels, pattern="default", filter_size=8):
+    """reference SubsetDCT.__init__ (cvtransforms.py:117-136): the pattern is ignored when filter_size == 4"""
+    if channels == 192:
+        return list(range(64)), list(range(64)), list(range(64))
+    table = SUBSET_FILTER4 if filter_size == 4 else SUBSET_DEFAULT
+    if filter_size != 4 and pattern != "default":
+        raise NotImplementedError("only the default pattern is restated")
+    return table[channels]
+
+
+def normalize_indices(channels):
+    """reference NormalizeDCT.__init__ (cvtransforms.py:168-183): ALWAYS the default (8x8) pattern -- the
+    transform is built without pattern/filter_size (datamgr.py:209-216), so for filter 4 the statistics do
+    not correspond to the selected coefficients.  Kept as is."""
+    y, cb, cr = SUBSET_DEFAULT[channels]
+    return list(y) + [64 + c for c in cb] + [128 + c for c in cr]
+
+
+def subset_aggregate_normalize(dct_y, dct_cb, dct_cr, channels, pattern="default", filter_size=8):
+    """CHW float32 planes -> [channels, S, S] (SubsetDCT + Aggregate + NormalizeDCT, cvtransforms.py:117-208)"""
+    sy, scb, scr = subset_indices(channels, pattern, filter_size)
+    agg = np.concatenate([dct_y[sy], dct_cb[scb], dct_cr[scr]], axis=0).astype(np.float32)
+    if channels < 192:
+        mean, std = load_stats()
+        idx = normalize_indices(channels)
+        m, s = mean[idx].astype(np.float32), std[idx].astype(np.float32)
+    else:
+        m, s = [a.astype(np.float32) for a in load_stats()]
+    # torch: t.sub_(m).div_(s) in float32, channel by channel (cvfunctional.py:181-201)
+    return (agg - m[:, None, None]) / s[:, None, None]
+
+
+# ------------------------------------------------------------------------------------------ unpinned (OpenCV arithmetic)
+def rgb_to_ycrcb_u8(img):
+    """8-bit RGB -> Y, Cr, Cb planes with OpenCV's fixed-point coefficients (14-bit, round to nearest):
+    Y = (4899 R + 9617 G + 1868 B + 8192) >> 14; Cr = ((R - Y) * 11682 + (128 << 14) + 8192) >> 14;
+    Cb = ((B - Y) * 9241 + (128 << 14) + 8192) >> 14, saturated.  [K] -- not checkable here."""
+    r, g, b = [img[..., i].astype(np.int64) for i in range(3)]
+    y = (4899 * r + 9617 * g + 1868 * b + 8192) >> 14
+    cr = ((r - y) * 11682 + (128 << 14) + 8192) >> 14
+    cb = ((b - y) * 9241 + (128 << 14) + 8192) >> 14
+    sat = lambda v: np.clip(v, 0, 255).astype(np.uint8)
+    return sat(y), sat(cr), sat(cb)
+
+
+def _bilinear(src, oh, ow):
+    """bilinear resize with half-pixel centres and edge clamp (OpenCV INTER_LINEAR geometry), float64"""
+    ih, iw = src.shape[:2]
+    ys = (np.arange(oh) + 0.5) * (ih / oh) - 0.5
+    xs = (np.arange(ow) + 0.5) * (iw / ow) - 0.5
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    fy = ys - y0; fx = xs - x0
+    y0c, y1c = np.clip(y0, 0, ih - 1), np.clip(y0 + 1, 0, ih - 1)
+    x0c, x1c = np.clip(x0, 0, iw - 1), np.clip(x0 + 1, 0, iw - 1)
+    s = src.astype(np.float64)
+    if s.ndim == 2:
+        s = s[..., None]
+    top = s[y0c][:, x0c] * (1 - fx)[None, :, None] + s[y0c][:, x1c] * fx[None, :, None]
+    bot = s[y1c][:, x0c] * (1 - fx)[None, :, None] + s[y1c][:, x1c] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    return out if src.ndim == 3 else out[..., 0]
+
+
+def resize_u8(img, oh, ow):
+    if (oh, ow) == img.shape[:2]:
+        return img.copy()
+    return np.clip(np.floor(_bilinear(img, oh, ow) + 0.5), 0, 255).astype(np.uint8)
+
+
+def halve_u8(plane):
+    """cv2.resize(plane, (w//2, h//2)) on uint8: exact 2x bilinear decimation = rounded 2x2 mean [K]"""
+    h, w = plane.shape
+    p = plane[:h // 2 * 2, :w // 2 * 2].astype(np.int32)
+    return ((p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+
+
+def center_crop(img, size):
+    """reference cvfunctional.py:358-368 + :324-355; Python round() is banker's rounding"""
+    h, w = img.shape[:2]
+    i, j = int(round((h - size) * 0.5)), int(round((w - size) * 0.5))
+    return img[i:i + size, j:j + size].copy()
+
+
+def transform_dct_size(img, size):
+    """reference cvfunctional.py:59-74.  OpenCV's COLOR_BGR2YCrCb yields planes Y, Cr, Cb but the code
+    unpacks them as y, cb, cr: the "cb" slot carries Cr.  Reproduced: returned order is (Y, Cr, Cb)."""
+    y, cr, cb = rgb_to_ycrcb_u8(img)
+    slot_cb, slot_cr = halve_u8(cr), halve_u8(cb)
+    return matrix2dct(y, size), matrix2dct(slot_cb, size), matrix2dct(slot_cr, size)
+
+
+def dct_eval_transform(filter_size=4, image_size_dct=16, channels=24, dct_pattern="default"):
+    """The composed evaluation transform of reference datamgr.py:192-219 for the matrix2dct path."""
+    if filter_size == 8:
+        raise NotImplementedError("the 8x8 path is JPEG-domain (TurboJPEG q=100 + jpeg2dct): SURVEY 8(f) rank 3")
+    S = image_size_dct
+
+    def tf(img_u8):
+        side = int(filter_size * S * 1.15)
+        h, w = img_u8.shape[:2]
+        if w <= h:
+            ow, oh = side, int(side * h / w)
+        else:
+            oh, ow = side, int(side * w / h)
+        x = resize_u8(img_u8, oh, ow)
+        x = center_crop(x, filter_size * S)
+        dy, dcb, dcr = transform_dct_size(x, filter_size)
+        up = lambda d: d if d.shape[:2] == (S, S) else _bilinear(d, S, S)     # UpScaleDCT, cvtransforms.py:56-64
+        planes = [np.ascontiguousarray(up(d).transpose(2, 0, 1)).astype(np.float32) for d in (dy, dcb, dcr)]   # ToTensorDCT
+        return subset_aggregate_normalize(*planes, channels=channels, pattern=dct_pattern, filter_size=filter_size)
+
+    return tf
+
+
+def rgb_eval_transform(image_size=32):
+    """Non-DCT branch (reference datamgr.py:83-88, homomorphic_eval.py:103-107): Resize(1.15x) -> CenterCrop ->
+    ToTensor -> Normalize(CIFAR mean/std)."""
+    mean = np.array([0.4914, 0.4822, 0.4465], np.float32)
+    std = np.array([0.2023, 0.1994, 0.2010], np.float32)
+
+    def tf(img_u8):
+        side = int(image_size * 1.15)
+        x = resize_u8(img_u8, side, side)
+        x = center_crop(x, image_size)
+        t = x.astype(np.float32).transpose(2, 0, 1) / 255.0
+        return (t - mean[:, None, None]) / std[:, None, None]
+
+    return tf

@@ -1,0 +1,65 @@
+"""Host logic: the circuit compiler and the noise-free integer circuit (no GPU)."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from dctfhe import compile as cc, models, params as P
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    return cc.compile_model(models.tiny_resnet_q(), calib, param_set=P.test_params()), calib
+
+
+def test_compile_is_deterministic(tiny):
+    from dctfhe import compile as cc, models, params as P
+    c, calib = tiny
+    c2 = cc.compile_model(models.tiny_resnet_q(), calib, param_set=P.test_params())
+    assert c.blob == c2.blob
+
+
+def test_blob_round_trips_through_oracle_parser(tiny):
+    from oracle import circuit_ref
+    c, _ = tiny
+    parsed = circuit_ref.parse_blob(c.blob)
+    assert len(parsed["ops"]) == len(c.ops) and len(parsed["tensors"]) == len(c.tensors)
+    for po, o in zip(parsed["ops"], c.ops):
+        assert po["type"] == o.type and po["dst"] == o.dst and list(po["ip"][:7]) == [int(x) for x in o.ip[:7]]
+
+
+def test_integer_circuit_reproduces_compile_time_values(tiny):
+    """the oracle interpreter, fed the calibration inputs, lands on the values the compiler saw"""
+    from dctfhe import compile as cc
+    from oracle import circuit_ref
+    c, calib = tiny
+    q = cc.act_quant(calib, c.in_scale, True, c.in_bits)
+    ph = (q.astype(np.int64).astype(np.uint64) << np.uint64(c.e_in)).reshape(q.shape[0], -1)
+    out, overflow = circuit_ref.run_clear(c.blob, ph)
+    assert not overflow
+    vals = (out + (np.uint64(1) << np.uint64(c.e_out - 1))).view(np.int64) >> np.int64(c.e_out)
+    assert vals.min() >= -8 and vals.max() <= 7 and len(np.unique(vals)) > 3
+
+
+def test_rounding_semantics_round_half_up():
+    from dctfhe import compile as cc
+    m = np.arange(-64, 60)
+    idx = cc.lut_index(m, 7, 1, True)
+    assert np.array_equal(idx, (m + 64 + 1) >> 1)
+    assert np.array_equal(cc.lut_centers(7, 1, 6, True), np.arange(64) * 2 - 64)
+    assert cc._acc_precision(-100, 100, 6, 0.0) == (8, 2, True)
+    assert cc._acc_precision(0, 15, 64, 0.0) == (4, 0, False)
+    assert cc._acc_precision(-16, 15, 64, 0.0) == (5, 0, True)
+
+
+def test_encodings_and_tiers_resnet20():
+    from dctfhe import compile as cc, models
+    from dctfhe.synthetic import synthetic_dct_batch
+    c = cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7))
+    luts = [o for o in c.ops if o.type == cc.OP_LUT]
+    assert len(luts) == 1 + 9 * 4 + 1 - 0      # stem + 4 sites per block + pool
+    assert sum(c.tensors[o.src0].C * c.tensors[o.src0].H * c.tensors[o.src0].W for o in luts) == 380992
+    assert all(o.w <= 6 for o in luts) and c.max_bit_width <= 16
+    for o in luts:
+        assert o.ip[3] >= 0 and c.param_set.tiers[o.ip[4]].logN - 1 >= o.w
+    assert c.expected_failures_per_image < 1e-3
+    assert "round_lut" in c.report()

@@ -1,0 +1,41 @@
+"""(1) host emulation of the device thread programs (FFT index math, whole PBS) against the oracle;
+(2) the C-ABI library loads and exports every symbol include/dctfhe.h declares; no compute without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_emulated_thread_programs(oracle):
+    d = os.path.join(ROOT, "tests", "emul")
+    subprocess.check_call(["make", "-C", d], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(d, "emul_pbs")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "EMUL OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_abi_exports_every_declared_symbol():
+    from dctfhe import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    hdr = open(os.path.join(ROOT, "include", "dctfhe.h")).read()
+    declared = sorted(set(re.findall(r"\b(dctfhe_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from dctfhe._lib import DctfheError
+    from dctfhe.engine import Context
+    with pytest.raises(DctfheError, match="no CPU path"):
+        Context(0)

@@ -1,0 +1,65 @@
+"""P4: the restated front-end against goldens captured from the reference's own functions
+(tools/make_goldens.py -> tests/golden/frontend_golden.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_golden.npz"))
+
+
+def test_stats_table_matches_reference():
+    from dctfhe import frontend
+    mean, std = frontend.load_stats()
+    assert mean.shape == std.shape == (192,)
+    assert np.array_equal(mean, G["stats_mean"]) and np.array_equal(std, G["stats_std"])
+    assert np.allclose(mean[:3], [-88.397, 0.014242, 0.0034117], rtol=1e-4)      # SURVEY appendix E spot values
+
+
+@pytest.mark.parametrize("plane,size,key", [("plane64", 4, "dct4_plane64"), ("plane64", 8, "dct8_plane64"), ("plane_odd", 4, "dct4_plane_odd")])
+def test_matrix2dct(plane, size, key):
+    from dctfhe import frontend
+    got = frontend.matrix2dct(G[plane], size)
+    assert got.shape == G[key].shape
+    assert np.allclose(got, G[key], rtol=0, atol=1e-9)
+
+
+def test_matrix2dct_dc_term():
+    from dctfhe import frontend
+    y = G["plane64"]
+    d = frontend.matrix2dct(y, 4)
+    assert np.isclose(d[0, 0, 0], (y[:4, :4].astype(np.int32) - 128).sum() / 4.0)
+
+
+@pytest.mark.parametrize("tag,ch,filt", [("c24f4", 24, 4), ("c48f8", 48, 8), ("c48f4", 48, 4)])
+def test_subset_aggregate_normalize(tag, ch, filt):
+    from dctfhe import frontend
+    sy, scb, scr = frontend.subset_indices(ch, "default", filt)
+    assert list(G[f"{tag}_subset_y"]) == list(sy) and list(G[f"{tag}_subset_cb"]) == list(scb) and list(G[f"{tag}_subset_cr"]) == list(scr)
+    assert list(G[f"{tag}_norm_subset"]) == frontend.normalize_indices(ch)
+    out = frontend.subset_aggregate_normalize(G[f"{tag}_y"], G[f"{tag}_cb"], G[f"{tag}_cr"], ch, "default", filt)
+    assert out.dtype == np.float32 and out.shape == G[f"{tag}_out"].shape
+    assert np.allclose(out, G[f"{tag}_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_normalize_index_quirk():
+    """filter 4 selects with the 4x4 table but normalises with the 8x8 default indices"""
+    from dctfhe import frontend
+    assert frontend.normalize_indices(24) == [0, 1, 2, 3, 4, 5, 8, 9, 10, 16, 17, 18, 24, 32, 64, 65, 67, 72, 88, 128, 129, 131, 136, 152]
+    assert frontend.subset_indices(24, "default", 4)[0] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13]
+
+
+def test_full_transform_self_consistency():
+    """cv2-dependent stages are unpinned (parity unpinned: OpenCV absent); check shape, dtype, determinism, crop geometry"""
+    from dctfhe import frontend, synthetic
+    x = synthetic.synthetic_dct_batch(3, seed=42)
+    assert x.shape == (3, 24, 16, 16) and x.dtype == np.float32 and np.isfinite(x).all()
+    assert np.array_equal(x, synthetic.synthetic_dct_batch(3, seed=42))
+    img = synthetic.synthetic_images(1, 42)[0]
+    up = frontend.resize_u8(img, 73, 73)
+    assert up.shape == (73, 73, 3) and frontend.center_crop(up, 64).shape == (64, 64, 3)
+    assert np.array_equal(frontend.center_crop(up, 64), up[4:68, 4:68])          # round(4.5) == 4 (banker's)
+    flat = np.full((8, 8, 3), 128, np.uint8)
+    y, cr, cb = frontend.rgb_to_ycrcb_u8(flat)
+    assert (y == 128).all() and (cr == 128).all() and (cb == 128).all()
+    assert np.array_equal(frontend.halve_u8(np.array([[1, 2], [3, 4]], np.uint8)), [[3]])

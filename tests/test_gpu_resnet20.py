@@ -1,0 +1,51 @@
+"""BASELINE config #1/#2 parity: ResNet-20 24x16^2 DCT trunk, full-size exact-evaluation tiers.
+decrypt(run(encrypt(q))) must equal the noise-free integer circuit on every one of the 64 outputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+@pytest.fixture(scope="module")
+def r20():
+    from dctfhe import models
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    from dctfhe.synthetic import synthetic_dct_batch
+    calib = synthetic_dct_batch(100, seed=7)
+    qm = compile_brevitas_qat_model(models.ResNet20QAT(bit_width=4, in_channels=24, img_size=16), calib, n_bits=5, rounding_threshold_bits=6,
+                                    p_error=0.01)
+    yield qm
+    qm.close()
+
+
+def _oracle(qm, q):
+    from oracle import circuit_ref
+    out, ov = circuit_ref.run_clear(qm.compiled.blob, qm.encode_input(q))
+    assert not ov
+    return qm.decode_output(out)
+
+
+def test_clear_mode_eight_images(r20):
+    from dctfhe.synthetic import synthetic_dct_batch
+    x = synthetic_dct_batch(8, seed=42)
+    q = r20.quantize_input(x)
+    assert np.array_equal(r20.forward_quantized(q, "disable"), _oracle(r20, q))
+
+
+def test_execute_one_image_bit_exact(r20):
+    from dctfhe.synthetic import synthetic_dct_batch
+    x = synthetic_dct_batch(1, seed=42)
+    q = r20.quantize_input(x)
+    want = _oracle(r20, q)
+    r20.fhe_circuit.keygen(seed=1)
+    got = r20.forward_quantized(q, "execute")
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "resnet20_execute_timing.json"), "w") as f:
+        json.dump(r20.last_timing, f)
+    assert got.shape == (1, 64)
+    assert np.array_equal(got, want), (got, want)
