@@ -112,8 +112,9 @@ def main():
     stats = qm.statistics()
 
     # this rank's shard of the global synthetic batch: image i -> rank i % world
+    from dctfhe.sharding import gather_in_image_order, shard_indices
     x_all = synthetic_dct_batch(B * world, seed=42)
-    x = x_all[rank::world]
+    x = x_all[shard_indices(B * world, rank, world)]
     q = qm.quantize_input(x)
     phases = qm.encode_input(q)
     sess = qm._session("execute", B)
@@ -149,13 +150,10 @@ def main():
     feats = torch.from_numpy(qm.dequantize_output(feats_q)).float()
     logits = feats @ torch.from_numpy(model.classifier_w).float().T + torch.from_numpy(model.classifier_b).float()
     if world > 1:
-        lg = logits.cuda()
-        gathered = [torch.empty_like(lg) for _ in range(world)]
-        dist.all_gather(gathered, lg)
+        all_logits = gather_in_image_order(logits.cuda(), world).cpu()      # one RCCL all_gather, global image order
         flags = torch.tensor([1.0 if exact else 0.0], device="cuda")
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         exact = bool(flags.item() > 0.5)
-        all_logits = torch.stack(gathered, dim=1).reshape(B * world, -1).cpu()      # back to global image order
     else:
         all_logits = logits
 

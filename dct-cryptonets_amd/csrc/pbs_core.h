@@ -49,6 +49,22 @@ HD void decompose(uint64_t v, int beta, int32_t* digs) {
   });
 }
 
+// digit LEV only (lev 0 most significant) of the same decomposition: the carry chain is walked from the
+// least significant digit up to LEV, the digits below are dropped
+template <int L, int LEV>
+HD int32_t decompose_level(uint64_t v, int beta) {
+  const int total = L * beta;
+  uint64_t x = (v + (1ULL << (63 - total))) >> (64 - total);
+  const uint64_t B = 1ULL << beta, half = B >> 1, mask = B - 1;
+  uint64_t carry = 0;
+  static_for<0, L - 1 - LEV>([&](auto) {
+    carry = (((x & mask) + carry) >= half) ? 1 : 0;
+    x >>= beta;
+  });
+  const uint64_t d = (x & mask) + carry;
+  return (int32_t)((int64_t)d - ((d >= half) ? (int64_t)B : 0));
+}
+
 // test-vector coefficient j (0 <= j < N) of the table T (2^w entries)
 HD uint64_t testvec_coeff(const int64_t* table, int w, int N, int j) {
   const int box = N >> w, half = box >> 1;
@@ -97,22 +113,27 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
 
     static_for<0, K + 1>([&](auto Pp) {
       constexpr int p = decltype(Pp)::value;
-      // rotate polynomial p through LDS
+      // rotate polynomial p through LDS.  The staged copy stays valid for the whole level loop (the FFT
+      // exchanges live in another region), so each gadget level re-reads it instead of parking all L digit
+      // planes in registers; the barriers inside the FFTs order the last read before the next write.
       static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[t + T * r] = acc[p][r]; });
-      sync();
-      int32_t dig[2 * P][L];
-      static_for<0, 2 * P>([&](auto R) {
-        constexpr int r = decltype(R)::value;
-        const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
-        uint64_t v = stage[src & (N - 1)];
-        if (src & N) v = (uint64_t)0 - v;
-        decompose<L>(v - acc[p][r], A.beta, dig[r]);
-      });
       sync();
       static_for<0, L>([&](auto Lv) {
         constexpr int lev = decltype(Lv)::value;
         cplx v[P];
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = cmk((double)dig[j][lev], (double)dig[P + j][lev]); });
+        static_for<0, P>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          double d2[2];
+          static_for<0, 2>([&](auto Hh) {
+            constexpr int h = decltype(Hh)::value;
+            constexpr int r = j + h * P;
+            const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
+            uint64_t x = stage[src & (N - 1)];
+            if (src & N) x = (uint64_t)0 - x;
+            d2[h] = (double)decompose_level<L, lev>(x - acc[p][r], A.beta);
+          });
+          v[j] = cmk(d2[0], d2[1]);
+        });
         fft_forward<G::LOGM, P>(v, t, tw, exch, sync);
         const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
         static_for<0, K + 1>([&](auto Q) {

@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard -> evaluate -> gather flow.
+The per-image evaluation is replaced by a deterministic function of the image so the order is checkable."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_eval(images):
+    return torch.from_numpy(np.stack([[im.sum() % 251, im.max(), im.min(), im[0, 0, 0]] for im in images]).astype(np.float32))
+
+
+def _worker(rank, world, port, n_images, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "dct-cryptonets_amd"))
+    from dctfhe.sharding import gather_in_image_order, shard_indices
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    imgs = np.random.default_rng(42).integers(0, 256, (n_images, 8, 8, 3))
+    idx = shard_indices(n_images, rank, world)
+    local = _fake_eval(imgs[idx])
+    dist.barrier()
+    full = gather_in_image_order(local, world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the max-over-ranks timing reduction of bench.py
+    if rank == 0:
+        torch.save({"full": full, "tmax": t}, out_path)
+    dist.destroy_process_group()
+
+
+def test_shard_gather_matches_serial(tmp_path):
+    world, n_images = 2, 6
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker, args=(world, _free_port(), n_images, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    imgs = np.random.default_rng(42).integers(0, 256, (n_images, 8, 8, 3))
+    assert torch.equal(got["full"], _fake_eval(imgs))
+    assert got["tmax"].item() == 2.0
+
+
+def test_shard_indices_partition():
+    sys.path.insert(0, os.path.join(ROOT, "dct-cryptonets_amd"))
+    from dctfhe.sharding import shard_indices
+    for world in (1, 2, 4, 8):
+        allidx = sorted(i for r in range(world) for i in shard_indices(64, r, world))
+        assert allidx == list(range(64))
+        assert all(len(shard_indices(64, r, world)) == 64 // world for r in range(world))
