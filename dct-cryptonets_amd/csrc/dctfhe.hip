@@ -103,17 +103,23 @@ struct dctfhe_session {
 };
 
 // ------------------------------------------------------------------------------------------ kernel dispatch
-// (logN, k, l, points per thread).  GROUPS is chosen so that a workgroup has 256 threads.
+// (logN, k, l, points per thread).  GROUPS is chosen so that a workgroup has 512 threads (2 waves per SIMD:
+// 8 points per thread keep the register arrays under 256 VGPRs; measured 1.6x over 16 points / 256 threads).
 #define PBS_CASES(X)                                                                                 \
-  X(8, 1, 1, 16) X(8, 1, 2, 16) X(8, 2, 2, 8) X(9, 1, 2, 16) X(9, 2, 1, 8) X(9, 1, 3, 8) X(9, 3, 2, 8)  \
-  X(10, 1, 1, 16) X(10, 1, 2, 16) X(10, 2, 1, 8) X(10, 2, 2, 8) X(10, 1, 3, 16)                      \
-  X(11, 1, 1, 16) X(11, 1, 2, 16) X(11, 1, 3, 16) X(12, 1, 1, 16) X(12, 1, 2, 16) X(12, 1, 3, 16)   \
-  X(13, 1, 1, 16) X(13, 1, 2, 16) X(13, 1, 3, 16)
+  X(8, 1, 1, 8) X(8, 1, 2, 8) X(8, 2, 2, 8) X(9, 1, 2, 16) X(9, 2, 1, 8) X(9, 1, 3, 8) X(9, 3, 2, 8)      \
+  X(10, 1, 1, 8) X(10, 1, 2, 8) X(10, 2, 1, 8) X(10, 2, 2, 8) X(10, 1, 3, 8)                           \
+  X(11, 1, 1, 8) X(11, 1, 2, 8) X(11, 1, 3, 8) X(12, 1, 1, 8) X(12, 1, 2, 8) X(12, 1, 3, 8)           \
+  X(13, 1, 1, 8) X(13, 1, 2, 8) X(13, 1, 3, 8) X(13, 1, 4, 8)
 
 template <int LOGN, int P>
 constexpr int groups_for() {
-  constexpr int T = fft_geom<LOGN - 1, P>::T;
-  return T >= 256 ? 1 : 256 / T;
+  using F = fft_geom<LOGN - 1, P>;
+  constexpr int T = F::T;
+  constexpr int per_group = F::EXCH_ELEMS * 16 + (1 << LOGN) * 8 + T * 4;      // exchange + rotation stage + warm-up sink
+  constexpr int by_lds = (160 * 1024 - F::TW_ELEMS * 16) / per_group;
+  int g = T >= 512 ? 1 : 512 / T;
+  while (g > 1 && g > by_lds) g >>= 1;
+  return g;
 }
 
 static int tier_ppt(const dctfhe_tier& t) {
@@ -129,7 +135,7 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
   if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
     using G = pbs_geom<LN, K_, L_, P_>;                                                              \
     constexpr int GR = groups_for<LN, P_>();                                                         \
-    const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES);                  \
+    const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES + G::T * 4);       \
     static bool attr_done = false;                                                                   \
     if (!attr_done) {                                                                                \
       HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, K_, L_, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -283,7 +289,9 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
     HIPCHK(hipStreamSynchronize(st));
     const int N = 1 << t.logN, M = N / 2, rows = (t.k + 1) * t.l;
     const size_t per_bit_polys = (size_t)rows * (t.k + 1);
-    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)t.n * per_bit_polys * M * sizeof(cplx)));
+    // PBS_PF_DIST extra (zero) key bits: the L2 warm-up of the last iterations reads past the key
+    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)(t.n + PBS_PF_DIST) * per_bit_polys * M * sizeof(cplx)));
+    HIPCHK(hipMemsetAsync(tk.d_bsk + (size_t)t.n * per_bit_polys * M, 0, (size_t)PBS_PF_DIST * per_bit_polys * M * sizeof(cplx), st));
     const int chunk = std::max(1, (int)std::min<size_t>(t.n, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
     uint64_t* d_std = nullptr;
     HIPCHK(hipMalloc(&d_std, (size_t)chunk * per_bit_polys * N * 8));
@@ -416,7 +424,7 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
   a.cts_small = d_small; a.count = count; a.n = t.n; a.beta = t.beta;
   a.bsk = K->tiers[tier].d_bsk; a.tw = K->tiers[tier].d_tw;
   a.tables = d_tables; a.w = w; a.table_idx = d_idx; a.hw = hw; a.nchan = nchan; a.e_offset = e_offset;
-  a.out = d_out; a.D_out = K->p.D; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy;
+  a.out = d_out; a.D_out = K->p.D; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy; a.bsk_wrap = 0; a.pf_parts = 16;
   const int h = tm ? tm->begin(tier) : -1;
   CHK(launch_pbs(t, a, K->ctx->stream));
   if (tm) tm->end(h);

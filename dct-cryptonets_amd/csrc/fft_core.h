@@ -193,8 +193,15 @@ HD int pass_addr(int t, int j) {
 //   exch      : LDS exchange buffer (G::EXCH_ELEMS), shared by the T threads of this polynomial
 //   sync      : barrier for those T threads.  Discipline: write; sync; gather; sync -- so the
 //               buffer is free again when the call returns.
-template <int LOGM, int P, class Sync>
-HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+// The exchange between pass i and i+1 only moves points among groups of W_i consecutive threads
+// (pass i+1 works inside blocks of W_i points, and the W_i threads that wrote a super-block of W_i*P points
+// are the ones that read it).  When W_i <= 64 that group sits inside one wave: the LDS queue of a wave is
+// in order, so no workgroup barrier is needed -- `wsync` (a compiler-level wave barrier) is enough.
+template <int LOGM, int P, class Sync, class WSync>
+HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
+#if defined(DCTFHE_ABLATE_FFT)   // timing experiments only
+  return;
+#endif
   using G = fft_geom<LOGM, P>;
   constexpr int S = G::S;
   // twist part 1: compile-time factor e^{i pi j T / N} = e^{2 pi i j / (4P)} on register j
@@ -222,9 +229,9 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
         static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = cmul(y[k], pw[k]); });
       }
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
-      sync();
+      if constexpr (W <= 64) wsync(); else sync();
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
-      sync();
+      if constexpr (W <= 64) wsync(); else sync();
     } else {
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = y[j]; });
     }
@@ -233,8 +240,11 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
 
 // Inverse transform (unnormalised; the 1/M lives in the Fourier key).
 //   v[0..P)   in : spectrum at addresses pass_addr<S-1>(t, j);  out: z_n for n = t + T*j, twist removed.
-template <int LOGM, int P, class Sync>
-HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+template <int LOGM, int P, class Sync, class WSync>
+HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
+#if defined(DCTFHE_ABLATE_FFT)
+  return;
+#endif
   using G = fft_geom<LOGM, P>;
   constexpr int S = G::S;
   static_for<0, S>([&](auto Irev) {
@@ -260,10 +270,11 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync) {
       static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v + g * R, y + g * R); });
     }
     if constexpr (i > 0) {
+      constexpr int Wp = G::weight(i - 1);   // exchange between pass i-1 and i: groups of W_{i-1} threads
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
-      sync();
+      if constexpr (Wp <= 64) wsync(); else sync();
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
-      sync();
+      if constexpr (Wp <= 64) wsync(); else sync();
     } else {
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = mul_root64<j*(64 / (4 * P)), -1>(y[j]); });
     }

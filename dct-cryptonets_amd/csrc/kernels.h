@@ -150,7 +150,7 @@ k_bsk_fourier(const uint64_t* __restrict__ polys, size_t npoly, const cplx* __re
   size_t q = (size_t)blockIdx.x * GROUPS + g;
   if (q >= npoly) q = npoly - 1;  // redundant work keeps every thread on the barriers
   cplx* exch = exch_all + (size_t)g * F::EXCH_ELEMS;
-  key_poly_to_fourier<LOGN, P>(polys + q * N, out + q * M, t, tw, exch, [] { __syncthreads(); });
+  key_poly_to_fourier<LOGN, P>(polys + q * N, out + q * M, t, tw, exch, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
 }
 
 // ------------------------------------------------------------------------------------------ K3 key switch
@@ -243,6 +243,8 @@ struct pbs_launch {
   int accumulate;
   uint64_t body_add;
   uint64_t* dummy;            // D_out+1 words: sink for the padded groups of the last workgroup
+  int bsk_wrap;               // cache experiments only (0 in the library)
+  int pf_parts;               // 0: no L2 warm-up; else each workgroup touches 1/pf_parts of the next key rows
 };
 
 template <int LOGN, int K, int L, int P, int GROUPS>
@@ -272,7 +274,11 @@ pbs_kernel(pbs_launch a) {
   A.D_out = a.D_out;
   A.accumulate = live ? a.accumulate : 0;
   A.body_add = a.body_add;
-  pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, [] { __syncthreads(); });
+  A.bsk_wrap = a.bsk_wrap;
+  A.pf_parts = a.pf_parts;
+  A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
+  uint32_t* pf_dump = reinterpret_cast<uint32_t*>(per_group + (size_t)GROUPS * (G::EXCH_BYTES + G::STAGE_BYTES)) + g * T;
+  pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
 }
 
 // ------------------------------------------------------------------------------------------ K1 conv2d

@@ -17,6 +17,10 @@
 
 namespace dctfhe {
 
+#ifndef PBS_PF_DIST
+#define PBS_PF_DIST 2
+#endif
+
 template <int LOGN, int K, int L, int P>
 struct pbs_geom {
   static constexpr int N = 1 << LOGN;
@@ -83,16 +87,30 @@ struct pbs_args {
   int D_out;
   int accumulate;             // 0: out = extract(ACC) (mask beyond K*N zeroed); 1: out += extract(ACC)
   uint64_t body_add;          // added to the body word (accumulate mode: the "- v" of a bit step)
+  int bsk_wrap;               // 0 = off; >0: key bit i reads BSK[i % bsk_wrap] (cache experiments only)
+  int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
 };
 
 // The whole bootstrap for one ciphertext, executed by thread t of its group.
-template <int LOGN, int K, int L, int P, class Sync>
-HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, Sync&& sync) {
+template <int LOGN, int K, int L, int P, class Sync, class WSync>
+HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
   using G = pbs_geom<LOGN, K, L, P>;
   constexpr int N = G::N, M = G::M, T = G::T;
   const int n = A.n;
   const int msh = 64 - LOGN - 2;
 
+  // L2 warm-up geometry: this workgroup owns lines [pf_line0, pf_line0 + pf_per) of every key bit
+  constexpr int PF_LINES = (int)(G::BSK_ELEMS_PER_KEYBIT * 16 / 128);
+  constexpr int PF_ROUNDS = (PF_LINES / 8 + T - 1) / T;      // touches per thread per iteration; covers pf_parts >= 8
+  const char* pf_ptr;
+  {
+    const int parts = A.pf_parts >= 8 ? A.pf_parts : PF_LINES;                 // pf_parts == 0: every thread re-touches line 0
+    const int per = (PF_LINES + parts - 1) / parts;
+    int line = A.pf_rank * per + (t < per ? t : per - 1);
+    if (line > PF_LINES - 1 - (PF_ROUNDS - 1) * T) line = PF_LINES - 1 - (PF_ROUNDS - 1) * T;
+    if (line < 0) line = 0;
+    pf_ptr = reinterpret_cast<const char*>(A.bsk + (size_t)PBS_PF_DIST * G::BSK_ELEMS_PER_KEYBIT) + (size_t)line * 128;
+  }
   uint64_t acc[K + 1][2 * P];
   {  // ACC = X^{-b~} * TV (trivial GLWE)
     const uint32_t bt = (uint32_t)(((A.ct_small[n] >> msh) + 1) >> 1) & (2 * N - 1);
@@ -107,7 +125,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
 
   for (int i = 0; i < n; i++) {
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
-    const cplx* bsk_i = A.bsk + (size_t)i * G::BSK_ELEMS_PER_KEYBIT;
+    const cplx* bsk_i = A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT;
     cplx out[K + 1][P];
     static_for<0, K + 1>([&](auto Q) { static_for<0, P>([&](auto J) { out[decltype(Q)::value][decltype(J)::value] = cmk(0.0, 0.0); }); });
 
@@ -134,21 +152,38 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
           });
           v[j] = cmk(d2[0], d2[1]);
         });
-        fft_forward<G::LOGM, P>(v, t, tw, exch, sync);
+        fft_forward<G::LOGM, P>(v, t, tw, exch, sync, wsync);
         const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
         static_for<0, K + 1>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
           static_for<0, P>([&](auto J) {
             constexpr int j = decltype(J)::value;
+#if defined(DCTFHE_ABLATE_BSK)   // timing experiments only (tools/exp_pbs.hip): no key traffic
+            out[q][j] = cfma(v[j], cmk(1.0 + j, 0.5 * q), out[q][j]);
+#else
             out[q][j] = cfma(v[j], row[(size_t)q * M + j * T + t], out[q][j]);
+#endif
           });
         });
       });
     });
 
+    // L2 warm-up.  Every CU walks the same key in near lock-step, so without help each key line is an HBM
+    // miss that all CUs of the XCD wait on together (measured: 128 ms -> 94 ms per launch with the key
+    // cache-resident).  Each workgroup therefore touches 1/pf_parts of the key two iterations ahead, one
+    // dword per 128-byte line; issued here, right after this iteration's last key load and before the two
+    // inverse transforms, the touches are long retired when the next vmcnt wait comes (vmcnt is in-order).
+    {  // straight-line on purpose: any branch or select chain here makes hipcc (ROCm 7.2) demote the register
+       // arrays to scratch (2.4 KB/lane).  The key buffer carries PBS_PF_DIST zero key bits of padding at its end.
+      uint32_t acc_pf = 0;
+      static_for<0, PF_ROUNDS>([&](auto Rr) { acc_pf ^= *reinterpret_cast<const uint32_t*>(pf_ptr + (size_t)decltype(Rr)::value * T * 128); });
+      pf_dump[t] = acc_pf;
+      pf_ptr += G::BSK_ELEMS_PER_KEYBIT * 16;
+    }
+
     static_for<0, K + 1>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      fft_inverse<G::LOGM, P>(out[q], t, tw, exch, sync);
+      fft_inverse<G::LOGM, P>(out[q], t, tw, exch, sync, wsync);
       static_for<0, P>([&](auto J) {
         constexpr int j = decltype(J)::value;
         acc[q][j] += f64_to_torus(out[q][j].re);
@@ -178,8 +213,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
 
 // Forward transform of one standard-domain key polynomial into the device layout [j][t], with
 // the 1/M of the inverse transform folded in.  Thread t of a T-thread group.
-template <int LOGN, int P, class Sync>
-HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* tw, cplx* exch, Sync&& sync) {
+template <int LOGN, int P, class Sync, class WSync>
+HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
   constexpr int N = 1 << LOGN, M = N / 2;
   using F = fft_geom<LOGN - 1, P>;
   constexpr int T = F::T;
@@ -188,7 +223,7 @@ HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* 
     constexpr int j = decltype(J)::value;
     v[j] = cmk((double)(int64_t)poly[t + T * j], (double)(int64_t)poly[t + T * j + M]);
   });
-  fft_forward<LOGN - 1, P>(v, t, tw, exch, sync);
+  fft_forward<LOGN - 1, P>(v, t, tw, exch, sync, wsync);
   const double inv = 1.0 / (double)M;
   static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; dst[j * T + t] = cmk(v[j].re * inv, v[j].im * inv); });
 }

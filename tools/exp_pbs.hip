@@ -8,12 +8,12 @@ using namespace dctfhe;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <int LOGN, int K, int L, int P, int GR>
-void run(int n, int beta, size_t count, int D) {
+void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   using G = pbs_geom<LOGN, K, L, P>;
   constexpr int N = G::N, M = G::M;
   std::vector<cplx> tw(G::F::TW_ELEMS);
   fill_twiddles<G::LOGM, P>(tw.data());
-  const size_t bsk_elems = (size_t)n * G::BSK_ELEMS_PER_KEYBIT;
+  const size_t bsk_elems = (size_t)((wrap ? wrap : n) + PBS_PF_DIST) * G::BSK_ELEMS_PER_KEYBIT;
   std::vector<cplx> bsk(bsk_elems);
   uint64_t st = 1;
   for (auto& c : bsk) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; c.re = (double)(int64_t)st / M; st = st * 6364136223846793005ULL + 1; c.im = (double)(int64_t)st / M; }
@@ -26,8 +26,8 @@ void run(int n, int beta, size_t count, int D) {
   CK(hipMemcpy(d_tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(d_bsk, bsk.data(), bsk_elems * 16, hipMemcpyHostToDevice));
   CK(hipMemcpy(d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
   pbs_launch a; a.cts_small = d_small; a.count = count; a.n = n; a.beta = beta; a.bsk = d_bsk; a.tw = d_tw; a.tables = d_tab; a.w = 4; a.table_idx = nullptr;
-  a.hw = 1; a.nchan = 1; a.e_offset = 0; a.out = d_out; a.D_out = D; a.accumulate = 0; a.body_add = 0; a.dummy = d_dummy;
-  const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES);
+  a.hw = 1; a.nchan = 1; a.e_offset = 0; a.out = d_out; a.D_out = D; a.accumulate = 0; a.body_add = 0; a.dummy = d_dummy; a.bsk_wrap = wrap; a.pf_parts = pf;
+  const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES + G::T * 4);
   CK(hipFuncSetAttribute((const void*)pbs_kernel<LOGN, K, L, P, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((count + GR - 1) / GR);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -39,7 +39,7 @@ void run(int n, int beta, size_t count, int D) {
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double fft = 5.0 * M * log2((double)M);
   const double fl = n * ((K + 1) * L * fft + (K + 1) * fft + (double)(K + 1) * (K + 1) * L * M * 8.0);
-  printf("N=%5d k=%d l=%d P=%2d groups=%d threads=%4d lds=%6zu: %zu cts %.1f ms -> %.0f PBS/s, %.2f TFLOP/s\n", N, K, L, P, GR, G::T * GR, lds, count, ms,
+  printf("pf=%d wrap=%d N=%5d k=%d l=%d P=%2d groups=%d threads=%4d lds=%6zu: %zu cts %.1f ms -> %.0f PBS/s, %.2f TFLOP/s\n", pf, wrap, N, K, L, P, GR, G::T * GR, lds, count, ms,
          count / (ms * 1e-3), fl * count / (ms * 1e-3) / 1e12);
   fflush(stdout);
   hipFree(d_tw); hipFree(d_bsk); hipFree(d_small); hipFree(d_out); hipFree(d_dummy); hipFree(d_tab);
