@@ -169,8 +169,9 @@ struct fft_geom {
   static constexpr int TW_TOTAL = geom_tw_offset(LOGM, P, S - 1);  // then T twist bases e^{i pi t/N}
   static constexpr int TW_ELEMS = TW_TOTAL + T;
   // exchange buffer index skew (bank spreading), LDS holds EXCH_ELEMS complex values
-  static HD int skew(int idx) { return idx + (idx >> 4); }
-  static constexpr int EXCH_ELEMS = M + (M >> 4);
+  // one padding element per P: conflict-free writes and at most 2-way reads on the first exchange (model: tools/lds_model.py)
+  static HD int skew(int idx) { return idx + (idx >> geom_logp(P)); }
+  static constexpr int EXCH_ELEMS = M + (M >> geom_logp(P));
 };
 
 // thread t's first point in a radix-R pass of weight W (its points are base + j*W)
@@ -197,8 +198,12 @@ HD int pass_addr(int t, int j) {
 // (pass i+1 works inside blocks of W_i points, and the W_i threads that wrote a super-block of W_i*P points
 // are the ones that read it).  When W_i <= 64 that group sits inside one wave: the LDS queue of a wave is
 // in order, so no workgroup barrier is needed -- `wsync` (a compiler-level wave barrier) is enough.
-template <int LOGM, int P, class Sync, class WSync>
-HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
+struct no_hook { HD void operator()() const {} };
+
+// `before_last` runs right after the last gather, before the last pass's butterflies: the caller uses it to put
+// its key loads in flight under that pass.
+template <int LOGM, int P, class Sync, class WSync, class Hook = no_hook>
+HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync, Hook&& before_last = Hook{}) {
 #if defined(DCTFHE_ABLATE_FFT)   // timing experiments only
   return;
 #endif
@@ -210,6 +215,7 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
     constexpr int i = decltype(I)::value;
     constexpr int R = G::radix(i);
     constexpr int W = G::weight(i);
+    if constexpr (i == S - 1) before_last();
     cplx y[P];
     if constexpr (R == P) {
       small_dft<P, 1, -1>::run(v, y);

@@ -17,6 +17,12 @@
 
 namespace dctfhe {
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DCTFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DCTFHE_SCHED_BARRIER() ((void)0)
+#endif
+
 #ifndef PBS_PF_DIST
 #define PBS_PF_DIST 2
 #endif
@@ -154,16 +160,24 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         });
         fft_forward<G::LOGM, P>(v, t, tw, exch, sync, wsync);
         const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
+        // Key loads are issued as one batch per output polynomial and only then consumed: left to itself hipcc
+        // (at this register pressure) emits load; s_waitcnt vmcnt(0); fma -- 16 serialized L2 round trips per row
+        // (measured 93 -> 72 ms per launch).  Issuing the first batch under the last FFT pass was tried and lost
+        // (more scratch traffic than latency hidden).
         static_for<0, K + 1>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
+          cplx kb[P];
           static_for<0, P>([&](auto J) {
             constexpr int j = decltype(J)::value;
 #if defined(DCTFHE_ABLATE_BSK)   // timing experiments only (tools/exp_pbs.hip): no key traffic
-            out[q][j] = cfma(v[j], cmk(1.0 + j, 0.5 * q), out[q][j]);
+            kb[j] = cmk(1.0 + j, 0.5 * q);
 #else
-            out[q][j] = cfma(v[j], row[(size_t)q * M + j * T + t], out[q][j]);
+            kb[j] = row[(size_t)q * M + j * T + t];
 #endif
           });
+          DCTFHE_SCHED_BARRIER();
+          static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; out[q][j] = cfma(v[j], kb[j], out[q][j]); });
+          DCTFHE_SCHED_BARRIER();
         });
       });
     });
