@@ -53,6 +53,8 @@ struct TierKeys {
   dctfhe_tier t{};
   uint64_t* d_ksk = nullptr;     // [D][lk][n+1]
   uint64_t* d_colsum = nullptr;  // [n+1]
+  int8_t* d_kskT = nullptr;      // signed byte limbs, [8(n+1) padded to 128][D*lk], for the MFMA key switch
+  int ncol_pad = 0;
   bool own_ksk = false;
   cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]
   cplx* d_tw = nullptr;
@@ -271,6 +273,8 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
     if (t.ksk_share >= 0) {
       tk.d_ksk = K->tiers[t.ksk_share].d_ksk;
       tk.d_colsum = K->tiers[t.ksk_share].d_colsum;
+      tk.d_kskT = K->tiers[t.ksk_share].d_kskT;
+      tk.ncol_pad = K->tiers[t.ksk_share].ncol_pad;
     } else {
       const size_t rows = (size_t)D * t.lk;
       HIPCHK(hipMalloc(&tk.d_ksk, rows * (t.n + 1) * 8));
@@ -279,6 +283,11 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
       hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)rows), dim3(256), 0, st, K->d_S, K->d_s, t.n, t.lk, t.betak, t.lwe_sigma, seed,
                          (uint64_t)(STREAM_KSK + 2 * ti), tk.d_ksk);
       hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.d_colsum);
+      if (rows % 64 == 0 && rows <= (1u << 17)) {
+        tk.ncol_pad = ((8 * (t.n + 1) + 127) / 128) * 128;
+        HIPCHK(hipMalloc(&tk.d_kskT, (size_t)tk.ncol_pad * rows));
+        hipLaunchKernelGGL(k_ksk_to_limbs, dim3(4096), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.ncol_pad, tk.d_kskT);
+      }
       HIPCHK(hipGetLastError());
     }
     // twiddles + Fourier bootstrap key
@@ -313,7 +322,7 @@ extern "C" int dctfhe_keys_destroy(dctfhe_keys* K) {
   hipSetDevice(K->ctx->device);
   hipFree(K->d_S); hipFree(K->d_s); hipFree(K->d_dummy);
   for (int i = 0; i < K->p.n_tiers; i++) {
-    if (K->tiers[i].own_ksk) { hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); }
+    if (K->tiers[i].own_ksk) { hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); if (K->tiers[i].d_kskT) hipFree(K->tiers[i].d_kskT); }
     hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw);
   }
   delete K;
@@ -409,9 +418,14 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
   const size_t total = count * (size_t)D;
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
   hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, D, shift, t.lk, t.betak, d_digits, d_bodies);
-  constexpr int CT = 16;
-  dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));
-  hipLaunchKernelGGL(k_ks_gemm<CT>, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_ksk, tk.d_colsum, t.n, t.betak, d_small);
+  if (tk.d_kskT) {   // matrix-core path: i8 digits x signed byte limbs of the key
+    dim3 g2((unsigned)(tk.ncol_pad / 128), (unsigned)((count + 127) / 128));
+    hipLaunchKernelGGL(k_ks_mfma, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_kskT, tk.d_colsum, t.n, t.betak, d_small);
+  } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64): integer VALU GEMM
+    constexpr int CT = 16;
+    dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));
+    hipLaunchKernelGGL(k_ks_gemm<CT>, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_ksk, tk.d_colsum, t.n, t.betak, d_small);
+  }
   HIPCHK(hipGetLastError());
   if (tm) tm->end(h);
   return 0;

@@ -218,6 +218,112 @@ k_ks_gemm(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
   }
 }
 
+// ---- key switch on the matrix cores -----------------------------------------------------------------
+// out[c][j] = fix[j] - sum_r dig'[c][r] * ksk[r][j] is a GEMM with a tiny-integer left operand (digits in
+// [0, 2^betak)) and a u64 right operand.  The key is re-expressed once, at keygen, as 8 signed byte limbs
+// (ksk = sum_k s_k 2^(8k), s_k in [-128,127], carries propagated), stored K-contiguous per output column:
+// kskT[(j*8 + k) * R + r].  Then C[c][j*8+k] = sum_r dig'[c][r] * s_k[r][j] is an i8 x i8 -> i32 GEMM for
+// v_mfma_i32_32x32x32_i8 (|C| <= R * 127 * 128 < 2^31 for R <= 2^17), and out = fix - sum_k C_k << 8k (mod 2^64).
+__global__ void k_ksk_to_limbs(const uint64_t* __restrict__ ksk, int R, int n, int ncol_pad /* 8*(n+1) rounded up */, int8_t* __restrict__ kskT) {
+  const size_t total = (size_t)R * (ncol_pad / 8);
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = x % R;
+    const size_t j = x / R;
+    uint64_t v = (j <= (size_t)n) ? ksk[r * (size_t)(n + 1) + j] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int b = (int)(v & 0xFF);
+      v >>= 8;
+      if (b >= 128) { b -= 256; v += 1; }
+      kskT[(j * 8 + k) * (size_t)R + r] = (int8_t)b;
+    }
+  }
+}
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// Block: 128 ciphertexts x 128 limb columns (16 output words), K step 64, 4 waves each owning a 64 x 64 quadrant
+// (2 x 2 MFMA tiles).  Both operands are K-contiguous, so a lane's 16-byte fragment is one ds_read_b128 and
+// the A and B fragments of a lane cover the same 16 k's whatever order the hardware walks them in.
+__global__ void __launch_bounds__(256)
+k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R, const int8_t* __restrict__ kskT,
+          const uint64_t* __restrict__ colsum, int n, int betak, uint64_t* __restrict__ out) {
+  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 16;     // +16 B per row: rows land on different bank groups
+  __shared__ __attribute__((aligned(16))) int8_t As[BM * LD];
+  __shared__ __attribute__((aligned(16))) int8_t Bs[BN * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const size_t c0 = (size_t)blockIdx.y * BM;
+  const size_t col0 = (size_t)blockIdx.x * BN;
+  v16i acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[a][b][e] = 0;
+  // staging assignment: 2 x 16 B of A and 2 x 16 B of B per thread per K step
+  const int srow = tid >> 2, sseg = (tid & 3) * 16;
+  const uint8_t* a_src[2];
+  const int8_t* b_src[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    size_t c = c0 + srow + 64 * u;
+    if (c >= count) c = count - 1;
+    a_src[u] = digits + c * (size_t)R + sseg;
+    b_src[u] = kskT + (col0 + srow + 64 * u) * (size_t)R + sseg;
+  }
+  const int fr = lane & 31, fh = (lane >> 5) * 16;
+  for (int k0 = 0; k0 < R; k0 += BK) {
+    v4i ga[2], gb[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      ga[u] = *reinterpret_cast<const v4i*>(a_src[u] + k0);
+      gb[u] = *reinterpret_cast<const v4i*>(b_src[u] + k0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      *reinterpret_cast<v4i*>(&As[(srow + 64 * u) * LD + sseg]) = ga[u];
+      *reinterpret_cast<v4i*>(&Bs[(srow + 64 * u) * LD + sseg]) = gb[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 32) {
+      v4i fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) fa[a] = *reinterpret_cast<const v4i*>(&As[(wm * 64 + a * 32 + fr) * LD + kk + fh]);
+#pragma unroll
+      for (int b = 0; b < 2; b++) fb[b] = *reinterpret_cast<const v4i*>(&Bs[(wn * 64 + b * 32 + fr) * LD + kk + fh]);
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  // epilogue: C tile layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); limb k = col & 7
+  const int limb = lane & 7;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      const size_t word = (col0 + wn * 64 + b * 32 + (lane & 31)) >> 3;     // output word j of this lane's column
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        uint64_t v = (uint64_t)(int64_t)acc[a][b][e] << (8 * limb);
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const size_t c = c0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (limb == 0 && c < count && word <= (size_t)n) {
+          const uint64_t fix = ((uint64_t)1 << (betak - 1)) * colsum[word] + (word == (size_t)n ? bodies[c] : 0);
+          out[c * (size_t)(n + 1) + word] = fix - v;
+        }
+      }
+    }
+}
+
 __global__ void k_ksk_colsum(const uint64_t* __restrict__ ksk, int R, int n, uint64_t* __restrict__ colsum) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j > n) return;

@@ -138,3 +138,17 @@ def test_fp64_peak_probe(gpu_ctx):
     tf = gpu_ctx.fp64_peak()
     print("measured f64 FMA peak: %.1f TFLOP/s" % tf)
     assert 20 < tf < 200
+
+
+def test_keyswitch_valu_fallback_bit_exact(gpu_ctx, oracle):
+    """D*lk not a multiple of 64: the engine takes the integer-VALU key-switch GEMM instead of the MFMA one."""
+    from dctfhe.engine import Keys, make_params
+    D = 1040
+    tier = dict(n=33, k=1, logN=9, l=2, beta=12, lk=3, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -45)
+    k = Keys(gpu_ctx, make_params(D, 33, [tier], 2.0 ** -50), seed=9)
+    try:
+        rng = np.random.default_rng(3)
+        cts = k.encrypt(rng.integers(0, 16, 37).astype(np.uint64) << np.uint64(59), seed=4)
+        assert np.array_equal(k.keyswitch(0, cts, shift=2), oracle.keyswitch(cts << np.uint64(2), k.export_ksk(0), 4))
+    finally:
+        k.close()
