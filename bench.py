@@ -35,6 +35,8 @@ def cpu_baseline(qm, stats, n_prime=16):
     """Times the CPU oracle (oracle/tfhe_ref.c, the C twin) on a bounded sample and extrapolates to images/s.
     Sample: per tier, `threads` ciphertexts through n'=16 blind-rotate iterations and a key switch onto n'+1
     columns -- both costs are exactly linear in n, so they are scaled by n/n' -- plus one 3x3 ciphertext conv."""
+    # the GPU box shares its host cores: keep to the one-GPU CPU share (16), and say how many were used
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     from oracle import ref_loader as R
     R.build()
     ps = qm.compiled.param_set
@@ -83,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "1")))
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "2")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -51,3 +51,19 @@ def test_ragged_batches(tiny):
     for B in (1, 3):
         q = qm.quantize_input(calib[10:10 + B])
         assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
+
+
+def test_cli_mirror_simulate_mode():
+    """the homomorphic_eval.py-compatible driver with the reference's flags (run_homomorphic_eval.sh ResNet20 CIFAR block)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "dct-cryptonets_amd", "homomorphic_eval.py"), "--dataset", "cifar10", "--model", "ResNet20qat",
+           "--dct_status", "--channels", "24", "--filter_size", "4", "--image_size_dct", "16", "--bit_width", "4", "--fhe_mode", "simulate",
+           "--calib_batch_size", "32", "--test_batch_size", "2", "--test_subset", "4", "--rounding_threshold_bits", "6", "--n_bits", "5",
+           "--p_error", "0.01"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(os.environ.get("TMPDIR", "/tmp")))
+    assert out.returncode == 0, out.stderr[-2000:]
+    for needle in ("Time for FHE compilation", "Max bit-width:", "it works in FHE!!", "Keygen time:", "Time per inference in FHE"):
+        assert needle in out.stdout, out.stdout
