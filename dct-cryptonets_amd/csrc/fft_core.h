@@ -121,23 +121,6 @@ struct small_dft {
   }
 };
 
-// powers b^0..b^(R-1) of a unit complex number with multiplication depth <= 4
-template <int R>
-HD void unit_powers(cplx b, cplx* pw) {
-  pw[0] = cmk(1.0, 0.0);
-  if constexpr (R > 1) pw[1] = b;
-  if constexpr (R > 2) pw[2] = csqr(b);
-  if constexpr (R > 3) pw[3] = cmul(pw[2], b);
-  if constexpr (R > 4) {
-    pw[4] = csqr(pw[2]);
-    static_for<5, (R < 8 ? R : 8)>([&](auto J) { constexpr int j = decltype(J)::value; pw[j] = cmul(pw[4], pw[j - 4]); });
-  }
-  if constexpr (R > 8) {
-    pw[8] = csqr(pw[4]);
-    static_for<9, R>([&](auto J) { constexpr int j = decltype(J)::value; pw[j] = cmul(pw[8], pw[j - 8]); });
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Geometry of the in-place mixed-radix transform for (log2 M, P)
 constexpr int geom_logp(int P) { return P == 16 ? 4 : P == 8 ? 3 : P == 4 ? 2 : -1; }
@@ -192,8 +175,7 @@ HD int pass_addr(int t, int j) {
 //             out: spectrum points at in-place addresses pass_addr<S-1>(t, j)
 //   tw        : table of G::TW_ELEMS entries: pass twiddles, then T twist bases e^{i pi t/N}
 //   exch      : LDS exchange buffer (G::EXCH_ELEMS), shared by the T threads of this polynomial
-//   sync      : barrier for those T threads.  Discipline: write; sync; gather; sync -- so the
-//               buffer is free again when the call returns.
+//   sync      : barrier for those T threads (see the barrier discipline inside).
 // The exchange between pass i and i+1 only moves points among groups of W_i consecutive threads
 // (pass i+1 works inside blocks of W_i points, and the W_i threads that wrote a super-block of W_i*P points
 // are the ones that read it).  When W_i <= 64 that group sits inside one wave: the LDS queue of a wave is
@@ -225,19 +207,22 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
     if constexpr (i < S - 1) {
       // twiddle e^{-2 pi i k m / (W R)}, m = t % W; pass 0 also carries twist part 2, e^{i pi t / N}
       const cplx b = tw[G::tw_offset(i) + (t % W)];
-      cplx pw[R];
-      unit_powers<R>(b, pw);
-      if constexpr (i == 0) {
-        const cplx c = tw[G::TW_TOTAL + t];
-        y[0] = cmul(y[0], c);
-        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = cmul(y[k], cmul(pw[k], c)); });
-      } else {
-        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; y[k] = cmul(y[k], pw[k]); });
+      // twiddle powers by a running product: two live values instead of R (the tree of squarings cost 24 more
+      // registers and measured no better noise: tests/emul/fftnoise.cpp)
+      {
+        cplx run = (i == 0) ? tw[G::TW_TOTAL + t] : cmk(1.0, 0.0);
+        if constexpr (i == 0) y[0] = cmul(y[0], run);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); y[k] = cmul(y[k], run); });
       }
+      // Barrier discipline.  A cross-wave exchange (W > 64) scatters over the whole buffer, so every wave must
+      // be done with whatever it was reading there (the wave-local gathers of the previous transform) BEFORE
+      // the first write, and the data must be complete before the gather: barrier; write; barrier; gather.
+      // The gather itself, and everything a wave-local exchange touches, stays inside the wave's own block,
+      // where program order (the LDS queue of a wave is in order) is enough.
+      if constexpr (W <= 64) wsync(); else sync();
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
       if constexpr (W <= 64) wsync(); else sync();
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
-      if constexpr (W <= 64) wsync(); else sync();
     } else {
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = y[j]; });
     }
@@ -259,14 +244,10 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
     constexpr int W = G::weight(i);
     if constexpr (i < S - 1) {
       const cplx b = tw[G::tw_offset(i) + (t % W)];
-      cplx pw[R];
-      unit_powers<R>(b, pw);
-      if constexpr (i == 0) {
-        const cplx c = tw[G::TW_TOTAL + t];
-        v[0] = cmulc(v[0], c);
-        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; v[k] = cmulc(v[k], cmul(pw[k], c)); });
-      } else {
-        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; v[k] = cmulc(v[k], pw[k]); });
+      {
+        cplx run = (i == 0) ? tw[G::TW_TOTAL + t] : cmk(1.0, 0.0);
+        if constexpr (i == 0) v[0] = cmulc(v[0], run);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); v[k] = cmulc(v[k], run); });
       }
     }
     cplx y[P];
@@ -280,6 +261,7 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
       if constexpr (Wp <= 64) wsync(); else sync();
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
+      // after a cross-wave gather other waves may still be reading this wave's block: barrier before anyone writes again
       if constexpr (Wp <= 64) wsync(); else sync();
     } else {
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = mul_root64<j*(64 / (4 * P)), -1>(y[j]); });

@@ -29,18 +29,19 @@ void run(int n, int beta) {
   std::vector<uint64_t> o_fft((size_t)count * (D + 1)), o_ex((size_t)count * (D + 1)), o_emu((size_t)count * (D + 1));
   ref_pbs_batch(cts.data(), count, n, bskf.data(), bsk.data(), 0, K, N, L, beta, table.data(), w, nullptr, D, o_fft.data());
   ref_pbs_batch(cts.data(), count, n, bskf.data(), bsk.data(), 1, K, N, L, beta, table.data(), w, nullptr, D, o_ex.data());
-  std::vector<cplx> tw(G::F::TW_ELEMS), bsk_dev((size_t)n * G::BSK_ELEMS_PER_KEYBIT), exch(G::F::EXCH_ELEMS);
+  std::vector<cplx> tw(G::F::TW_ELEMS), bsk_dev((size_t)(n + PBS_PF_DIST) * G::BSK_ELEMS_PER_KEYBIT), exch(G::F::EXCH_ELEMS);
+  std::vector<uint32_t> pfd(T);
   fill_twiddles<G::LOGM, P>(tw.data());
   std::vector<uint64_t> stage(N);
   std::barrier bar(T);
   auto worker = [&](int t) {
     auto sync = [&] { bar.arrive_and_wait(); };
     const size_t npoly = (size_t)n * rows * (K + 1);
-    for (size_t q = 0; q < npoly; q++) key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), exch.data(), sync);
+    for (size_t q = 0; q < npoly; q++) key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), exch.data(), sync, sync);
     for (int c = 0; c < count; c++) {
       pbs_args A; A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data(); A.table = table.data(); A.w = w;
-      A.out = o_emu.data() + (size_t)c * (D + 1); A.D_out = D; A.accumulate = 0; A.body_add = 0;
-      pbs_thread<LOGN, K, L, P>(A, t, tw.data(), stage.data(), exch.data(), sync); sync();
+      A.out = o_emu.data() + (size_t)c * (D + 1); A.D_out = D; A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.pf_rank = 0;
+      pbs_thread<LOGN, K, L, P>(A, t, tw.data(), stage.data(), exch.data(), pfd.data(), sync, sync); sync();
     }
   };
   std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(worker, t); for (auto& x : th) x.join();
@@ -58,8 +59,7 @@ void run(int n, int beta) {
               lg(ee), lg(ef), lg(em), lg(ef) - 0.5 * std::log2(n), lg(em) - 0.5 * std::log2(n));
 }
 int main() {
-  run<11, 1, 2, 16>(16, 17);
-  run<12, 1, 2, 16>(8, 17);
-  run<12, 1, 2, 16>(8, 12);
+  run<12, 1, 3, 8>(8, 12);
+  run<11, 1, 3, 8>(16, 12);
   return 0;
 }
