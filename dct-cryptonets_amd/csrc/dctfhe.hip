@@ -111,7 +111,7 @@ struct dctfhe_session {
   X(8, 1, 1, 8) X(8, 1, 2, 8) X(8, 2, 2, 8) X(9, 1, 2, 16) X(9, 2, 1, 8) X(9, 1, 3, 8) X(9, 3, 2, 8)      \
   X(10, 1, 1, 8) X(10, 1, 2, 8) X(10, 2, 1, 8) X(10, 2, 2, 8) X(10, 1, 3, 8)                           \
   X(11, 1, 1, 8) X(11, 1, 2, 8) X(11, 1, 3, 8) X(12, 1, 1, 8) X(12, 1, 2, 8) X(12, 1, 3, 8)           \
-  X(13, 1, 1, 8) X(13, 1, 2, 8) X(13, 1, 3, 8) X(13, 1, 4, 8)
+  X(13, 1, 1, 8) X(13, 1, 2, 8) X(13, 1, 3, 8)
 
 template <int LOGN, int P>
 constexpr int groups_for() {
@@ -226,7 +226,7 @@ static int check_params(const dctfhe_params* p) {
     const dctfhe_tier& t = p->tiers[i];
     if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
     if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
-    if (t.l * t.beta > 63 || t.l < 1) return fail("tier %d: bad bootstrap gadget", i);
+    if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || (t.l >= 2 && t.beta > 16)) return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2)", i);
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);

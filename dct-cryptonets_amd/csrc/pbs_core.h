@@ -59,22 +59,6 @@ HD void decompose(uint64_t v, int beta, int32_t* digs) {
   });
 }
 
-// digit LEV only (lev 0 most significant) of the same decomposition: the carry chain is walked from the
-// least significant digit up to LEV, the digits below are dropped
-template <int L, int LEV>
-HD int32_t decompose_level(uint64_t v, int beta) {
-  const int total = L * beta;
-  uint64_t x = (v + (1ULL << (63 - total))) >> (64 - total);
-  const uint64_t B = 1ULL << beta, half = B >> 1, mask = B - 1;
-  uint64_t carry = 0;
-  static_for<0, L - 1 - LEV>([&](auto) {
-    carry = (((x & mask) + carry) >= half) ? 1 : 0;
-    x >>= beta;
-  });
-  const uint64_t d = (x & mask) + carry;
-  return (int32_t)((int64_t)d - ((d >= half) ? (int64_t)B : 0));
-}
-
 // test-vector coefficient j (0 <= j < N) of the table T (2^w entries)
 HD uint64_t testvec_coeff(const int64_t* table, int w, int N, int j) {
   const int box = N >> w, half = box >> 1;
@@ -137,26 +121,35 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
 
     static_for<0, K + 1>([&](auto Pp) {
       constexpr int p = decltype(Pp)::value;
-      // rotate polynomial p through LDS.  The staged copy stays valid for the whole level loop (the FFT
-      // exchanges live in another region), so each gadget level re-reads it instead of parking all L digit
-      // planes in registers; the barriers inside the FFTs order the last read before the next write.
+      // rotate polynomial p through LDS: every coefficient is read (rotated) and decomposed once; level 0 goes
+      // straight to the transform, the other digits (<= 16 bits each: beta <= 16 whenever l >= 2) wait packed in
+      // one register per coefficient.  (Re-reading + re-decomposing per level cost 15% more: integer VALU.)
       static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[t + T * r] = acc[p][r]; });
       sync();
+      // one rotated read + one full decomposition per coefficient; the digits of levels >= 1 wait packed in a register
+      static_assert(L <= 3, "packing holds two deferred digits");
+      uint32_t packed[2 * P];
+      double first[2 * P];
+      static_for<0, 2 * P>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
+        uint64_t x = stage[src & (N - 1)];
+        if (src & N) x = (uint64_t)0 - x;
+        int32_t dg[L];
+        decompose<L>(x - acc[p][r], A.beta, dg);
+        first[r] = (double)dg[0];
+        uint32_t pk = 0;
+        if constexpr (L > 1) pk = (uint32_t)(uint16_t)(int16_t)dg[1];
+        if constexpr (L > 2) pk |= (uint32_t)(uint16_t)(int16_t)dg[2] << 16;
+        packed[r] = pk;
+      });
       static_for<0, L>([&](auto Lv) {
         constexpr int lev = decltype(Lv)::value;
         cplx v[P];
         static_for<0, P>([&](auto J) {
           constexpr int j = decltype(J)::value;
-          double d2[2];
-          static_for<0, 2>([&](auto Hh) {
-            constexpr int h = decltype(Hh)::value;
-            constexpr int r = j + h * P;
-            const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
-            uint64_t x = stage[src & (N - 1)];
-            if (src & N) x = (uint64_t)0 - x;
-            d2[h] = (double)decompose_level<L, lev>(x - acc[p][r], A.beta);
-          });
-          v[j] = cmk(d2[0], d2[1]);
+          if constexpr (lev == 0) v[j] = cmk(first[j], first[P + j]);
+          else v[j] = cmk((double)(int16_t)(packed[j] >> (16 * (lev - 1))), (double)(int16_t)(packed[P + j] >> (16 * (lev - 1))));
         });
         fft_forward<G::LOGM, P>(v, t, tw, exch, sync, wsync);
         const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
