@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "2")))
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

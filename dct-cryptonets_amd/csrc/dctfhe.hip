@@ -105,8 +105,9 @@ struct dctfhe_session {
 };
 
 // ------------------------------------------------------------------------------------------ kernel dispatch
-// (logN, k, l, points per thread).  GROUPS is chosen so that a workgroup has 512 threads (2 waves per SIMD:
-// 8 points per thread keep the register arrays under 256 VGPRs; measured 1.6x over 16 points / 256 threads).
+// (logN, k, l, points per thread).  8 points per thread keep the register arrays under 256 VGPRs, i.e. 2 waves
+// per SIMD (measured 1.6x over 16 points per thread at 1 wave per SIMD); GROUPS packs ciphertexts up to 256
+// threads per workgroup, so that two workgroups share a CU (N = 8192 needs all 512 threads for one ciphertext).
 #define PBS_CASES(X)                                                                                 \
   X(8, 1, 1, 8) X(8, 1, 2, 8) X(8, 2, 2, 8) X(9, 1, 2, 16) X(9, 2, 1, 8) X(9, 1, 3, 8) X(9, 3, 2, 8)      \
   X(10, 1, 1, 8) X(10, 1, 2, 8) X(10, 2, 1, 8) X(10, 2, 2, 8) X(10, 1, 3, 8)                           \
@@ -119,7 +120,7 @@ constexpr int groups_for() {
   constexpr int T = F::T;
   constexpr int per_group = F::EXCH_ELEMS * 16 + (1 << LOGN) * 8 + T * 4;      // exchange + rotation stage + warm-up sink
   constexpr int by_lds = (160 * 1024 - F::TW_ELEMS * 16) / per_group;
-  int g = T >= 512 ? 1 : 512 / T;
+  int g = T >= 256 ? 1 : 256 / T;      // two 256-thread workgroups per CU beat one of 512 (+10..20%, profiles/r01_exp_wg.log)
   while (g > 1 && g > by_lds) g >>= 1;
   return g;
 }

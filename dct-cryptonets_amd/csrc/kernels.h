@@ -363,6 +363,9 @@ pbs_kernel(pbs_launch a) {
   unsigned char* per_group = smem_raw + G::TW_BYTES;
   for (int x = threadIdx.x; x < G::F::TW_ELEMS; x += blockDim.x) tw[x] = a.tw[x];
   __syncthreads();
+#if defined(DCTFHE_STAGGER)   // experiment: desynchronise co-resident workgroups by half a transform
+  if ((blockIdx.x >> 8) & 1) for (int z = 0; z < DCTFHE_STAGGER; z++) __builtin_amdgcn_s_sleep(64);
+#endif
   const int g = threadIdx.x / T, t = threadIdx.x % T;
   size_t e = (size_t)blockIdx.x * GROUPS + g;
   const bool live = e < a.count;

@@ -23,6 +23,12 @@ namespace dctfhe {
 #define DCTFHE_SCHED_BARRIER() ((void)0)
 #endif
 
+// key loads in flight per thread between two waits: 8 spilled more than it hid, 2 exposed the latency
+// (measured on T5 / B / T4: 4 is +10..20% over 8)
+#ifndef PBS_KEY_BATCH
+#define PBS_KEY_BATCH 4
+#endif
+
 #ifndef PBS_PF_DIST
 #define PBS_PF_DIST 2
 #endif
@@ -157,20 +163,24 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         // (at this register pressure) emits load; s_waitcnt vmcnt(0); fma -- 16 serialized L2 round trips per row
         // (measured 93 -> 72 ms per launch).  Issuing the first batch under the last FFT pass was tried and lost
         // (more scratch traffic than latency hidden).
+        constexpr int KB = (P > PBS_KEY_BATCH) ? PBS_KEY_BATCH : P;      // key loads in flight per thread and batch
         static_for<0, K + 1>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
-          cplx kb[P];
-          static_for<0, P>([&](auto J) {
-            constexpr int j = decltype(J)::value;
+          static_for<0, P / KB>([&](auto Hb) {
+            constexpr int j0 = decltype(Hb)::value * KB;
+            cplx kb[KB];
+            static_for<0, KB>([&](auto J) {
+              constexpr int j = decltype(J)::value;
 #if defined(DCTFHE_ABLATE_BSK)   // timing experiments only (tools/exp_pbs.hip): no key traffic
-            kb[j] = cmk(1.0 + j, 0.5 * q);
+              kb[j] = cmk(1.0 + j, 0.5 * q);
 #else
-            kb[j] = row[(size_t)q * M + j * T + t];
+              kb[j] = row[(size_t)q * M + (j0 + j) * T + t];
 #endif
+            });
+            DCTFHE_SCHED_BARRIER();
+            static_for<0, KB>([&](auto J) { constexpr int j = decltype(J)::value; out[q][j0 + j] = cfma(v[j0 + j], kb[j], out[q][j0 + j]); });
+            DCTFHE_SCHED_BARRIER();
           });
-          DCTFHE_SCHED_BARRIER();
-          static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; out[q][j] = cfma(v[j], kb[j], out[q][j]); });
-          DCTFHE_SCHED_BARRIER();
         });
       });
     });
