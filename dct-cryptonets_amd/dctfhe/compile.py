@@ -373,13 +373,21 @@ def _assign_encodings(circ):
         for s in ([o.src0, o.src1] if o.type == OP_ADD else [o.src0]):
             req[s] = need if req[s] is None else min(req[s], need)
     T[circ.input_tensor].e = req[circ.input_tensor]
+    # a table whose output is only ever added (or decrypted) tolerates a noisier, cheaper tier
+    amplified = [False] * len(T)
+    for o in ops:
+        if o.type in (OP_CONV, OP_SUMPOOL):
+            amplified[o.src0] = True
+    for o in reversed(ops):          # an add passes the requirement of its result on to its operands
+        if o.type == OP_ADD and amplified[o.dst]:
+            amplified[o.src0] = amplified[o.src1] = True
     for o in ops:
         if o.type == OP_LUT:
             T[o.dst].e = req[o.dst]
             shift = (63 - o.p) - T[o.src0].e
             assert shift >= 0
             ps = circ.param_set
-            tier = ps.tier_for_width(o.w)
+            tier = ps.tier_for_width(o.w, coarse=not amplified[o.dst])
             if o.w > ps.tiers[tier].logN - 1:
                 raise ValueError("table wider than the ring")
             o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]

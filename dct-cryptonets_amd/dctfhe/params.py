@@ -54,7 +54,8 @@ class ParamSet:
     D: int
     tiers: list
     bit_tier: int                      # index of the one-bit (rounding) tier
-    table_tier_for_w: dict             # table input width w -> tier index
+    table_tier_for_w: dict             # table input width w -> tier index (outputs that feed a convolution / pooling)
+    coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
     input_sigma: float = 0.0
     fft_noise_c: float = 2.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
 
@@ -66,10 +67,11 @@ class ParamSet:
     def n_max(self):
         return max(t.n for t in self.tiers)
 
-    def tier_for_width(self, w):
-        for ww in sorted(self.table_tier_for_w):
+    def tier_for_width(self, w, coarse=False):
+        table = self.coarse_tier_for_w if (coarse and self.coarse_tier_for_w) else self.table_tier_for_w
+        for ww in sorted(table):
             if w <= ww:
-                return self.table_tier_for_w[ww]
+                return table[ww]
         raise ValueError(f"no tier for a table of {w} input bits")
 
 
@@ -114,7 +116,11 @@ def default_params():
     t5 = TierSpec("T5", n=864, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
     t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0)
     b = TierSpec("B", n=660, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
-    return ParamSet(D=8192, tiers=[t6, t5, t4, b], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0})
+    # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
+    # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
+    t6a = TierSpec("T6a", n=864, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0)
+    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0},
+                    coarse_tier_for_w={4: 2, 5: 1, 6: 4})
 
 
 def test_params():
