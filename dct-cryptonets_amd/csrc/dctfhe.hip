@@ -460,16 +460,18 @@ static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::mi
 
 // exact rounding + table look-up on `count` ciphertexts, in place on d_work (already shifted / offset)
 struct LutScratch { uint8_t* digits; uint64_t* bodies; uint64_t* small; int64_t* bit_tables; size_t chunk; };
-static int dev_round_lut(dctfhe_keys* K, int bit_tier, int tab_tier, uint64_t* d_work, size_t count, int p, int r, const int64_t* d_tables,
-                         int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm) {
+// rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe)
+static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, uint64_t* d_work, size_t count, int p, int r,
+                         const int64_t* d_tables, int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm) {
   const size_t L = (size_t)K->p.D + 1;
   for (size_t c0 = 0; c0 < count; c0 += sc.chunk) {
     const size_t cn = std::min(sc.chunk, count - c0);
     uint64_t* w0 = d_work + c0 * L;
     for (int i = 0; i < r; i++) {
-      CHK(dev_keyswitch(K, bit_tier, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm));
+      const int bt = (bit_tier_coarse >= 0 && i >= coarse_from) ? bit_tier_coarse : bit_tier;
+      CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm));
       const int vlog = 62 - p + i;
-      CHK(dev_pbs(K, bit_tier, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm));
+      CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm));
     }
     CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm));
     CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm));
@@ -561,7 +563,7 @@ extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_keys* K, int bit_tier, i
     hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work, d_work, count, L, 0, 1ULL << (63 - p + r - 1));
     HIPCHK(hipGetLastError());
   }
-  CHK(dev_round_lut(K, bit_tier, tab_tier, d_work, count, p, r, d_tab, w, d_idx, 1, 1, sc, nullptr));
+  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work, count, p, r, d_tab, w, d_idx, 1, 1, sc, nullptr));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cts_out, d_work, count * L * 8, hipMemcpyDeviceToHost));
   free_lut_scratch(&sc);
@@ -673,10 +675,12 @@ extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, d
           s->flops_f64 += ein * tier_flops(P->tiers[tt]);
           s->key_bytes_per_pass += key_bytes(P->tiers[tt]);
         }
-        if (r > 0 && bt >= 0 && bt < P->n_tiers) {
-          s->pbs_count[bt] += (int64_t)(ein * r); s->ks_count[bt] += (int64_t)(ein * r);
-          s->flops_f64 += ein * r * tier_flops(P->tiers[bt]);
-          s->key_bytes_per_pass += r * key_bytes(P->tiers[bt]);
+        for (int st = 0; st < r; st++) {
+          const int b2 = (o.ip[7] >= 0 && st >= o.ip[8]) ? o.ip[7] : bt;
+          if (b2 < 0 || b2 >= P->n_tiers) continue;
+          s->pbs_count[b2] += (int64_t)ein; s->ks_count[b2] += (int64_t)ein;
+          s->flops_f64 += ein * tier_flops(P->tiers[b2]);
+          s->key_bytes_per_pass += key_bytes(P->tiers[b2]);
         }
         break;
       }
@@ -702,6 +706,7 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
       const int tt = o.ip[4], bt = o.ip[5], r = o.ip[1], w = o.ip[2];
       if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) { delete s; return fail("op %zu names a tier the keys lack", i); }
       if (w > keys->p.tiers[tt].logN - 1) { delete s; return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt); }
+      if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) { delete s; return fail("op %zu names a coarse bit tier the keys lack", i); }
     }
   // tensor liveness: free a buffer after its last reader; reuse freed buffers of sufficient size
   const int nt = (int)circ->tensors.size();
@@ -842,7 +847,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
           hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * L)), dim3(256), 0, st, src, dst, E, L, shift, add);
           HIPCHK(hipGetLastError());
           tm.end(h);
-          CHK(dev_round_lut(K, bt, tt, dst, E, p, r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
+          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
         }
         break;
       }

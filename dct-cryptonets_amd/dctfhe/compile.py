@@ -98,6 +98,7 @@ class OpInfo:
     nu2: float = 1.0
     note: str = ""
     pfail: float = 0.0
+    coarse_from: int = -1             # rounding steps i >= coarse_from run on the one-level bit tier
 
 
 @dataclass
@@ -151,6 +152,7 @@ class CompiledCircuit:
             elif o.type == OP_LUT:
                 head += (f" {{p={o.p}, lsbs_removed={o.r}, table_bits={o.w}, signed={int(o.signed)}, shift={o.ip[3]}, "
                          f"tier={ps.tiers[o.ip[4]].name}" + (f", bit_tier={ps.tiers[o.ip[5]].name}" if o.r else "") +
+                         (f", steps>={o.ip[8]}:{ps.tiers[o.ip[7]].name}" if (o.r and o.ip[7] >= 0 and o.ip[8] < o.r) else "") +
                          f", tables={o.ip[6]}, p_fail/elt={o.pfail:.1e}}}  // {o.note}")
             lines.append(f"{head} : [{s.C}x{s.H}x{s.W}] -> [{d.C}x{d.H}x{d.W}] e={d.e}")
         lines.append(f"// expected table failures per image (noise model): {self.expected_failures_per_image:.2e}")
@@ -391,6 +393,7 @@ def _assign_encodings(circ):
             if o.w > ps.tiers[tier].logN - 1:
                 raise ValueError("table wider than the ring")
             o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]
+            o.ip[7], o.ip[8] = (ps.bit_tier_coarse if ps.bit_tier_coarse is not None else -1), o.r      # refined by _estimate_noise
             o.lp[0] = (1 << 62) if o.signed else 0
             enc = (o.table_values.astype(object) * (1 << T[o.dst].e)) % (1 << 64)
             o.payload = np.array(enc, dtype=np.uint64).view(np.int64)
@@ -416,17 +419,29 @@ def _estimate_noise(circ):
             T[o.dst].var = o.ip[0] ** 2 * s.var
         else:
             tt = ps.tiers[o.ip[4]]
-            v_in = s.var * 4.0 ** o.ip[3]
-            pf = 0.0
-            if o.r > 0:
-                bt = ps.tiers[o.ip[5]]
-                vb = P.var_pbs_out(bt, ps.fft_noise_c)
-                for i in range(o.r):
-                    v = 4.0 ** (o.p - i) * (v_in + i * vb) + P.var_keyswitch(ps.D, bt) + P.var_modswitch(bt)
-                    pf += P.p_fail(0.25, v)
-                v_in = v_in + o.r * vb
-            v = v_in + P.var_keyswitch(ps.D, tt) + P.var_modswitch(tt)
-            pf += P.p_fail(2.0 ** -(o.w + 2), v)
+            v_in0 = s.var * 4.0 ** o.ip[3]
+            v_tab_in = P.var_keyswitch(ps.D, tt) + P.var_modswitch(tt)
+
+            def site_pfail(coarse_from):
+                pf_, v_ = 0.0, v_in0
+                if o.r > 0:
+                    bt = ps.tiers[o.ip[5]]
+                    v_bit_in = P.var_keyswitch(ps.D, bt) + P.var_modswitch(bt)
+                    for i in range(o.r):
+                        pf_ += P.p_fail(0.25, 4.0 ** (o.p - i) * v_ + v_bit_in)
+                        step_tier = ps.tiers[o.ip[7]] if (i >= coarse_from and o.ip[7] >= 0) else bt
+                        v_ += P.var_pbs_out(step_tier, ps.fft_noise_c)
+                return pf_ + P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
+
+            pf = site_pfail(o.r)
+            if o.r > 0 and o.ip[7] >= 0:
+                # earliest step from which the one-level bit tier keeps the site within 2x of its all-precise failure rate
+                budget = max(2.0 * pf, 1e-12)
+                cf = o.r
+                while cf > 0 and site_pfail(cf - 1) <= budget:
+                    cf -= 1
+                o.coarse_from = o.ip[8] = cf
+                pf = site_pfail(cf)
             o.pfail = pf
             total += pf * n_elt
             T[o.dst].var = P.var_pbs_out(tt, ps.fft_noise_c)

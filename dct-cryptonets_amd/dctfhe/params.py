@@ -56,6 +56,7 @@ class ParamSet:
     bit_tier: int                      # index of the one-bit (rounding) tier
     table_tier_for_w: dict             # table input width w -> tier index (outputs that feed a convolution / pooling)
     coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
+    bit_tier_coarse: int = None        # one-level twin of the bit tier for the last rounding steps of a site
     input_sigma: float = 0.0
     fft_noise_c: float = 2.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
 
@@ -119,8 +120,12 @@ def default_params():
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
     t6a = TierSpec("T6a", n=864, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0)
-    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 1, 6: 4})
+    # Ba: one-level bit tier.  The output of rounding step i is amplified by 2^(p-j) only in the later steps j > i,
+    # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
+    # site, the first step from which Ba is safe.
+    ba = TierSpec("Ba", n=660, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
+    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0},
+                    coarse_tier_for_w={4: 2, 5: 1, 6: 4}, bit_tier_coarse=5)
 
 
 def test_params():
