@@ -233,6 +233,15 @@ class _Builder:
         self.ops.append(op)
         return _Act(q, a.scale, tid, a.lo * K * K, a.hi * K * K)
 
+    def lut_to_conv(self, a, fn, per_channel, rounding, out_scale, note):
+        """table site whose output feeds a convolution; wide sites are split into a cheap noisy look-up followed by an
+        identity 'refresh' bootstrap on a small ring (ParamSet.refresh_min_w)"""
+        y = self.lut(a, fn, per_channel, rounding, out_scale, note)
+        op = self.ops[-1]
+        if self.ps.refresh_min_w is not None and op.w >= self.ps.refresh_min_w and y.lo >= 0:
+            y = self.lut(y, lambda vals: vals, False, False, out_scale, note + " (refresh)")
+        return y
+
     def lut(self, a, fn, per_channel, rounding, out_scale, note):
         """fn(values[ntab or 1, n]) -> integer outputs; values are message values of `a` (ints).
         rounding=True: `a` is an accumulator, calibrated range + rounding to rtb bits;
@@ -300,7 +309,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
             x = act_quant(np.maximum(x, 0), s_r, False, bits) * s_r
         return act_quant(x, s_q0, True, bits)
 
-    a = bld.lut(acc, chan_fn(model.bn1, acc.scale, stem_post), True, True, s_q0, "stem: bn1+relu+quant_out")
+    a = bld.lut_to_conv(acc, chan_fn(model.bn1, acc.scale, stem_post), True, True, s_q0, "stem: bn1+relu+quant_out")
 
     for bi, blk in enumerate(model.blocks):
         # C1 -> BN1 -> relu1 (u4)                                            backbone.py:94-96
@@ -309,7 +318,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
         _bn_calibrate(blk.BN1, real1)
         h1 = np.maximum(_bn_apply(blk.BN1, real1), 0)
         s_r1 = act_scale(h1, False, bits)
-        r1 = bld.lut(acc1, chan_fn(blk.BN1, acc1.scale, lambda x, s=s_r1: act_quant(np.maximum(x, 0), s, False, bits)), True, True, s_r1,
+        r1 = bld.lut_to_conv(acc1, chan_fn(blk.BN1, acc1.scale, lambda x, s=s_r1: act_quant(np.maximum(x, 0), s, False, bits)), True, True, s_r1,
                      f"block{bi}: BN1+relu1")
         # C2 -> BN2 -> quant_out (s4)                                        backbone.py:97-99
         acc2 = bld.conv(r1, blk.C2, bits)

@@ -57,6 +57,7 @@ class ParamSet:
     table_tier_for_w: dict             # table input width w -> tier index (outputs that feed a convolution / pooling)
     coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
     bit_tier_coarse: int = None        # one-level twin of the bit tier for the last rounding steps of a site
+    refresh_min_w: int = None          # tables this wide that feed a convolution are split: coarse look-up + small-ring refresh
     input_sigma: float = 0.0
     fft_noise_c: float = 2.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
 
@@ -124,8 +125,11 @@ def default_params():
     # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
     # site, the first step from which Ba is safe.
     ba = TierSpec("Ba", n=660, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
-    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba], bit_tier=3, table_tier_for_w={4: 2, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 1, 6: 4}, bit_tier_coarse=5)
+    # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
+    # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
+    t4r = TierSpec("T4r", n=864, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
+    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
+                    coarse_tier_for_w={4: 2, 5: 1, 6: 4}, bit_tier_coarse=5, refresh_min_w=6)
 
 
 def test_params():

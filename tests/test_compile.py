@@ -56,8 +56,11 @@ def test_encodings_and_tiers_resnet20():
     from dctfhe.synthetic import synthetic_dct_batch
     c = cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7))
     luts = [o for o in c.ops if o.type == cc.OP_LUT]
-    assert len(luts) == 1 + 9 * 4 + 1 - 0      # stem + 4 sites per block + pool
-    assert sum(c.tensors[o.src0].C * c.tensors[o.src0].H * c.tensors[o.src0].W for o in luts) == 380992
+    sites = [o for o in luts if "(refresh)" not in o.note]
+    assert len(sites) == 1 + 9 * 4 + 1          # stem + 4 sites per block + pool
+    assert sum(c.tensors[o.src0].C * c.tensors[o.src0].H * c.tensors[o.src0].W for o in sites) == 380992
+    # conv-feeding 6-bit sites are split into a coarse look-up and a small-ring refresh (stem + one per block)
+    assert len(luts) - len(sites) == 10 and all(o.r == 0 and o.w <= 4 for o in luts if "(refresh)" in o.note)
     assert all(o.w <= 6 for o in luts) and c.max_bit_width <= 16
     for o in luts:
         assert o.ip[3] >= 0 and c.param_set.tiers[o.ip[4]].logN - 1 >= o.w
