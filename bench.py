@@ -31,6 +31,21 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not list it, so the live FMA probe is reported beside it)
 
 
+def measured_hbm_traffic(kernel_tag, cts_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/pmc_summary.py; FETCH_SIZE and
+    WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected inside this run).  Scaled by ciphertexts per
+    launch; None when the summary has no entry for this kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    if not os.path.exists(path):
+        return None
+    prof = json.load(open(path))
+    for k, v in prof.items():
+        if kernel_tag in k.replace(" ", "") and v.get("launches"):
+            per_ct = v["hbm_bytes_per_launch"] / v.get("cts_per_launch", cts_per_launch)
+            return per_ct * cts_per_launch
+    return None
+
+
 def cpu_baseline(qm, stats, n_prime=16):
     """Times the CPU oracle (oracle/tfhe_ref.c, the C twin) on a bounded sample and extrapolates to images/s.
     Sample: per tier, `threads` ciphertexts through n'=16 blind-rotate iterations and a key switch onto n'+1
@@ -206,7 +221,7 @@ def main():
                        "expected_table_failures_per_image": qm.compiled.expected_failures_per_image},
             "roofline": {"bound": "hbm", "kernel": f"pbs_kernel<logN={td.logN},k={td.k},l={td.l}> (tier {td.name})",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": avg_launch_s * 1e3, "cts_per_launch": cts_per_launch,
+                         "traffic": measured_hbm_traffic(f"pbs_kernel<{td.logN},{td.k},{td.l},", cts_per_launch), "avg_launch_ms": avg_launch_s * 1e3, "cts_per_launch": cts_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the blind rotate is f64-VALU/LDS bound (SURVEY 8d); see roofline_fp64 for the bounding roof"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_SPEC_TFLOPS, "unit": "TFLOP/s",

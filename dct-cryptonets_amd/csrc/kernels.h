@@ -387,7 +387,13 @@ pbs_kernel(pbs_launch a) {
   A.pf_parts = a.pf_parts;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
   uint32_t* pf_dump = reinterpret_cast<uint32_t*>(per_group + (size_t)GROUPS * (G::EXCH_BYTES + G::STAGE_BYTES)) + g * T;
-  pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
+  if constexpr (T <= 64) {
+    // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
+    // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
+    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
+  } else {
+    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
+  }
 }
 
 // ------------------------------------------------------------------------------------------ K1 conv2d

@@ -3,8 +3,9 @@
 Mirrors reference dct-cryptonets/homomorphic_eval.py:89-443 and the flag set of io_utils.py:13-90 (same names,
 defaults and choices) on top of the dctfhe engine.  Differences forced by the environment: datasets cannot be
 downloaded (homomorphic_eval.py:139-142 needs the network), so images are synthetic and seeded
-(dctfhe/synthetic.py) with random labels; Brevitas checkpoints are not importable yet, so --checkpoint_path
-falls back to the reference's own "random weights" branch (homomorphic_eval.py:254-256) with the same warning.
+(dctfhe/synthetic.py) with random labels; --checkpoint_path
+is read by dctfhe/checkpoint.py (weights, BatchNorm statistics, classifier; activation scales are re-calibrated) and a
+missing file takes the reference's own "random weights" branch (homomorphic_eval.py:254-256) with the same warning.
 Printed lines keep the reference's wording so logs stay comparable.
 """
 import argparse
@@ -103,10 +104,14 @@ def main():
 
     name = params.model if params.model.endswith("qat") else params.model + "qat"
     model = models.model_dict[name](bit_width=params.bit_width, in_channels=in_ch, img_size=img, num_classes=params.num_classes)
-    if params.checkpoint_path:
-        print("WARNING: Brevitas checkpoints are not importable yet; ignoring --checkpoint_path")
-    print("WARNING: No checkpoint loaded. Using random weights (for testing only)")           # :254-256
-    print("Results will NOT be meaningful!")
+    if params.checkpoint_path and os.path.isfile(params.checkpoint_path):                     # :247-253
+        from dctfhe import checkpoint
+        meta, unused = checkpoint.load_checkpoint(params.checkpoint_path, model)
+        print(f"Loaded checkpoint {params.checkpoint_path} (epoch {meta.get('epoch')}, prec1 {meta.get('prec1')}); "
+              f"{len(unused)} quantiser-scale entries re-derived from the calibration batch")
+    else:
+        print("WARNING: No checkpoint loaded. Using random weights (for testing only)")       # :254-256
+        print("Results will NOT be meaningful!")
 
     calib_data, _ = make(params.calib_batch_size, params.seed + 100)
     print("\nCompiling FHE Model (this can take up to 10 minutes for larger networks)...")
