@@ -51,9 +51,9 @@ def cpu_baseline(qm, stats, n_prime=16):
     Sample: per tier, `threads` ciphertexts through n'=16 blind-rotate iterations and a key switch onto n'+1
     columns -- both costs are exactly linear in n, so they are scaled by n/n' -- plus one 3x3 ciphertext conv."""
     # the GPU box shares its host cores: keep to the one-GPU CPU share (16), and say how many were used
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     from oracle import ref_loader as R
     R.build()
+    R.lib().ref_set_num_threads(min(16, os.cpu_count() or 1))
     ps = qm.compiled.param_set
     threads = R.lib().ref_num_threads()
     D = ps.D

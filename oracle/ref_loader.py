@@ -61,6 +61,7 @@ def lib():
                                       C.POINTER(RefTier), i64p, C.c_int, C.c_void_p, u64p]
     L.ref_round_lut_batch.restype = C.c_int
     L.ref_num_threads.restype = C.c_int
+    L.ref_set_num_threads.argtypes = [C.c_int]
     _LIB = L
     return L
 

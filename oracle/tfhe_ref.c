@@ -48,6 +48,14 @@ void ref_gen_binary_key(uint64_t seed, int len, uint8_t *key) {
   }
 }
 
+void ref_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

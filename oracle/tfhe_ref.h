@@ -97,6 +97,7 @@ int ref_round_lut_batch(const uint64_t *cts_in, int count, int D, int p, int r,
                         uint64_t *cts_out);
 
 int ref_num_threads(void);
+void ref_set_num_threads(int n);
 
 #ifdef __cplusplus
 }
