@@ -114,13 +114,11 @@ struct dctfhe_session {
   X(11, 1, 1, 8) X(11, 1, 2, 8) X(11, 1, 3, 8) X(12, 1, 1, 8) X(12, 1, 2, 8) X(12, 1, 3, 8)           \
   X(13, 1, 1, 8) X(13, 1, 2, 8) X(13, 1, 3, 8)
 
-template <int LOGN, int P>
+template <int LOGN, int K_, int L_, int P>
 constexpr int groups_for() {
-  using F = fft_geom<LOGN - 1, P>;
-  constexpr int T = F::T;
-  constexpr int per_group = F::EXCH_ELEMS * 16 + (1 << LOGN) * 8 + T * 4;      // exchange + rotation stage + warm-up sink
-  constexpr int by_lds = (160 * 1024 - F::TW_ELEMS * 16) / per_group;
-  int g = T >= 256 ? 1 : 256 / T;      // two 256-thread workgroups per CU beat one of 512 (+10..20%, profiles/r01_exp_wg.log)
+  using G = pbs_geom<LOGN, K_, L_, P>;
+  constexpr int by_lds = (160 * 1024 - G::TW_BYTES) / G::GROUP_BYTES;
+  int g = G::T >= 256 ? 1 : 256 / G::T;   // two 256-thread workgroups per CU beat one of 512 (+10..20%, profiles/r01_exp_wg.log)
   while (g > 1 && g > by_lds) g >>= 1;
   return g;
 }
@@ -137,8 +135,8 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
 #define X(LN, K_, L_, P_)                                                                            \
   if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
     using G = pbs_geom<LN, K_, L_, P_>;                                                              \
-    constexpr int GR = groups_for<LN, P_>();                                                         \
-    const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES + G::T * 4);       \
+    constexpr int GR = groups_for<LN, K_, L_, P_>();                                                 \
+    const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                 \
     static bool attr_done = false;                                                                   \
     if (!attr_done) {                                                                                \
       HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, K_, L_, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -170,7 +168,7 @@ static int launch_bsk_fourier(const dctfhe_tier& t, const uint64_t* polys, size_
 #define X(LN, K_, L_, P_)                                                                            \
   if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
     using F = fft_geom<LN - 1, P_>;                                                                  \
-    constexpr int GR = groups_for<LN, P_>();                                                         \
+    constexpr int GR = groups_for<LN, K_, L_, P_>();                                                 \
     const size_t lds = (size_t)F::TW_ELEMS * 16 + (size_t)GR * F::EXCH_ELEMS * 16;                   \
     static bool attr_done = false;                                                                   \
     if (!attr_done) {                                                                                \

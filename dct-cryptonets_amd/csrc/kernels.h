@@ -370,8 +370,11 @@ pbs_kernel(pbs_launch a) {
   size_t e = (size_t)blockIdx.x * GROUPS + g;
   const bool live = e < a.count;
   if (!live) e = a.count - 1;  // padded groups redo the last ciphertext and drop the result
-  cplx* exch = reinterpret_cast<cplx*>(per_group + (size_t)g * (G::EXCH_BYTES + G::STAGE_BYTES));
-  uint64_t* stage = reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(exch) + G::EXCH_BYTES);
+  unsigned char* mine = per_group + (size_t)g * G::GROUP_BYTES;
+  cplx* exch = reinterpret_cast<cplx*>(mine);
+  uint64_t* stage = reinterpret_cast<uint64_t*>(mine + G::STAGE_OFFSET);     // aliases the exchange buffer when G::ALIAS
+  uint64_t* accl = reinterpret_cast<uint64_t*>(mine + G::SHARED_BYTES);
+  uint32_t* pf_dump = reinterpret_cast<uint32_t*>(mine + G::SHARED_BYTES + G::ACCL_BYTES);
   pbs_args A;
   A.ct_small = a.cts_small + e * (size_t)(a.n + 1);
   A.n = a.n; A.beta = a.beta; A.bsk = a.bsk;
@@ -386,13 +389,12 @@ pbs_kernel(pbs_launch a) {
   A.bsk_wrap = a.bsk_wrap;
   A.pf_parts = a.pf_parts;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
-  uint32_t* pf_dump = reinterpret_cast<uint32_t*>(per_group + (size_t)GROUPS * (G::EXCH_BYTES + G::STAGE_BYTES)) + g * T;
   if constexpr (T <= 64) {
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
     // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
-    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
   } else {
-    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
   }
 }
 

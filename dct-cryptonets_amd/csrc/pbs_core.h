@@ -25,6 +25,11 @@ namespace dctfhe {
 
 // key loads in flight per thread between two waits: 8 spilled more than it hid, 2 exposed the latency
 // (measured on T5 / B / T4: 4 is +10..20% over 8)
+// accumulator polynomials kept in LDS rather than registers: -1 = per-kernel rule (pbs_geom::NL_AUTO), 0/1 force
+#ifndef PBS_LDS_POLYS
+#define PBS_LDS_POLYS (-1)
+#endif
+
 #ifndef PBS_KEY_BATCH
 #define PBS_KEY_BATCH 4
 #endif
@@ -42,9 +47,22 @@ struct pbs_geom {
   static constexpr int T = F::T;
   static constexpr int ROWS = (K + 1) * L;
   static constexpr size_t BSK_ELEMS_PER_KEYBIT = (size_t)ROWS * (K + 1) * M;  // complex
-  // LDS per group (bytes)
+  // LDS per group (bytes).  The rotation stage aliases the FFT exchange buffer (every stage read is over before
+  // the first exchange write of the same polynomial: barrier discipline in pbs_thread), and the first NL
+  // accumulator polynomials live in LDS instead of registers (32 VGPRs each at P = 8).
+  // measured (profiles/r01_exp_lds_acc.log): +11..13% where the register arrays spilled (k = 2, or three levels),
+  // -2..3% where they did not (one level, k = 1) -- hence the rule.  The body polynomial K always stays in registers.
+  static constexpr int NL_AUTO = (K >= 2 || L >= 3) ? 1 : 0;
+  static constexpr int NL = PBS_LDS_POLYS < 0 ? NL_AUTO : (PBS_LDS_POLYS < K ? PBS_LDS_POLYS : K);
   static constexpr int STAGE_BYTES = N * 8;
   static constexpr int EXCH_BYTES = F::EXCH_ELEMS * 16;
+  // the stage only aliases the exchange buffer when an LDS-resident polynomial needs the room: aliasing costs one
+  // extra barrier per register polynomial and iteration (measured -3% on the one-level N = 8192 kernel)
+  static constexpr bool ALIAS = NL > 0;
+  static constexpr int STAGE_OFFSET = ALIAS ? 0 : EXCH_BYTES;
+  static constexpr int SHARED_BYTES = ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
+  static constexpr int ACCL_BYTES = NL * N * 8;
+  static constexpr int GROUP_BYTES = SHARED_BYTES + ACCL_BYTES + T * 4;   // + L2 warm-up sink
   static constexpr int TW_BYTES = F::TW_ELEMS * 16;  // shared by all groups of a workgroup
 };
 
@@ -89,9 +107,9 @@ struct pbs_args {
 
 // The whole bootstrap for one ciphertext, executed by thread t of its group.
 template <int LOGN, int K, int L, int P, class Sync, class WSync>
-HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
+HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, uint64_t* accl, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
   using G = pbs_geom<LOGN, K, L, P>;
-  constexpr int N = G::N, M = G::M, T = G::T;
+  constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
   const int n = A.n;
   const int msh = 64 - LOGN - 2;
 
@@ -110,7 +128,14 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
   uint64_t acc[K + 1][2 * P];
   {  // ACC = X^{-b~} * TV (trivial GLWE)
     const uint32_t bt = (uint32_t)(((A.ct_small[n] >> msh) + 1) >> 1) & (2 * N - 1);
-    static_for<0, K>([&](auto Pp) { constexpr int p = decltype(Pp)::value; static_for<0, 2 * P>([&](auto R) { acc[p][decltype(R)::value] = 0; }); });
+    static_for<0, K>([&](auto Pp) {
+      constexpr int p = decltype(Pp)::value;
+      static_for<0, 2 * P>([&](auto R) {
+        constexpr int r = decltype(R)::value;
+        if constexpr (p < NL) accl[p * N + t + T * r] = 0; else acc[p][r] = 0;
+      });
+    });
+    if constexpr (NL > 0) sync();
     static_for<0, 2 * P>([&](auto R) {
       constexpr int r = decltype(R)::value;
       const uint32_t idx = ((uint32_t)(t + T * r) + bt) & (2 * N - 1);
@@ -130,8 +155,14 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       // rotate polynomial p through LDS: every coefficient is read (rotated) and decomposed once; level 0 goes
       // straight to the transform, the other digits (<= 16 bits each: beta <= 16 whenever l >= 2) wait packed in
       // one register per coefficient.  (Re-reading + re-decomposing per level cost 15% more: integer VALU.)
-      static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[t + T * r] = acc[p][r]; });
-      sync();
+      // LDS-resident polynomials are rotated straight out of their home array; the others go through the stage,
+      // which shares memory with the exchange buffer: barrier before the (cross-wave) stage write so that nobody
+      // is still gathering there, barrier after it; the next transform's leading barrier covers the reads.
+      if constexpr (p >= NL) {
+        if constexpr (G::ALIAS) sync();
+        static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[t + T * r] = acc[p][r]; });
+        sync();
+      }
       // one rotated read + one full decomposition per coefficient; the digits of levels >= 1 wait packed in a register
       static_assert(L <= 3, "packing holds two deferred digits");
       uint32_t packed[2 * P];
@@ -139,10 +170,12 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       static_for<0, 2 * P>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
-        uint64_t x = stage[src & (N - 1)];
+        uint64_t x, own;
+        if constexpr (p < NL) { x = accl[p * N + (src & (N - 1))]; own = accl[p * N + t + T * r]; }
+        else                  { x = stage[src & (N - 1)]; own = acc[p][r]; }
         if (src & N) x = (uint64_t)0 - x;
         int32_t dg[L];
-        decompose<L>(x - acc[p][r], A.beta, dg);
+        decompose<L>(x - own, A.beta, dg);
         first[r] = (double)dg[0];
         uint32_t pk = 0;
         if constexpr (L > 1) pk = (uint32_t)(uint16_t)(int16_t)dg[1];
@@ -203,8 +236,13 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       fft_inverse<G::LOGM, P>(out[q], t, tw, exch, sync, wsync);
       static_for<0, P>([&](auto J) {
         constexpr int j = decltype(J)::value;
-        acc[q][j] += f64_to_torus(out[q][j].re);
-        acc[q][P + j] += f64_to_torus(out[q][j].im);
+        if constexpr (q < NL) {
+          accl[q * N + t + T * j] += f64_to_torus(out[q][j].re);
+          accl[q * N + t + T * (P + j)] += f64_to_torus(out[q][j].im);
+        } else {
+          acc[q][j] += f64_to_torus(out[q][j].re);
+          acc[q][P + j] += f64_to_torus(out[q][j].im);
+        }
       });
     });
   }
@@ -217,7 +255,9 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       constexpr int r = decltype(R)::value;
       const int c = t + T * r;
       const int dst = p * N + (c == 0 ? 0 : N - c);
-      const uint64_t v = (c == 0) ? acc[p][r] : (uint64_t)0 - acc[p][r];
+      uint64_t av;
+      if constexpr (p < NL) av = accl[p * N + c]; else av = acc[p][r];
+      const uint64_t v = (c == 0) ? av : (uint64_t)0 - av;
       if (A.accumulate) o[dst] += v; else o[dst] = v;
     });
   });

@@ -43,9 +43,9 @@ static int run_case(int n, int beta, int w, double sigma_bsk) {
   std::vector<cplx> tw(G::F::TW_ELEMS);
   fill_twiddles<G::LOGM, P>(tw.data());
   std::vector<cplx> bsk_dev((size_t)(n + PBS_PF_DIST) * G::BSK_ELEMS_PER_KEYBIT);
-  std::vector<uint64_t> stage(N);
+  std::vector<unsigned char> shared(G::SHARED_BYTES);   // rotation stage aliases the exchange buffer, as on the device
+  std::vector<uint64_t> accl((size_t)G::NL * N + 1);
   std::vector<uint32_t> pfd(T);
-  std::vector<cplx> exch(G::F::EXCH_ELEMS);
   std::vector<uint64_t> emu_out((size_t)count * (D + 1), 0x1234);
   {
     std::barrier bar(T);
@@ -53,13 +53,13 @@ static int run_case(int n, int beta, int w, double sigma_bsk) {
       auto sync = [&] { bar.arrive_and_wait(); };
       const size_t npoly = (size_t)n * rows * (K + 1);
       for (size_t q = 0; q < npoly; q++)
-        key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), exch.data(), sync, sync);
+        key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), reinterpret_cast<cplx*>(shared.data()), sync, sync);
       for (int c = 0; c < count; c++) {
         pbs_args A;
         A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data();
         A.table = table.data(); A.w = w; A.out = emu_out.data() + (size_t)c * (D + 1); A.D_out = D;
         A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.pf_rank = 0;
-        pbs_thread<LOGN, K, L, P>(A, t, tw.data(), stage.data(), exch.data(), pfd.data(), sync, sync);
+        pbs_thread<LOGN, K, L, P>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
         sync();
       }
     };

@@ -27,7 +27,7 @@ void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   CK(hipMemcpy(d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_tab, tab, sizeof tab, hipMemcpyHostToDevice));
   pbs_launch a; a.cts_small = d_small; a.count = count; a.n = n; a.beta = beta; a.bsk = d_bsk; a.tw = d_tw; a.tables = d_tab; a.w = 4; a.table_idx = nullptr;
   a.hw = 1; a.nchan = 1; a.e_offset = 0; a.out = d_out; a.D_out = D; a.accumulate = 0; a.body_add = 0; a.dummy = d_dummy; a.bsk_wrap = wrap; a.pf_parts = pf;
-  const size_t lds = G::TW_BYTES + (size_t)GR * (G::EXCH_BYTES + G::STAGE_BYTES + G::T * 4);
+  const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;
   CK(hipFuncSetAttribute((const void*)pbs_kernel<LOGN, K, L, P, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((count + GR - 1) / GR);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
