@@ -31,6 +31,25 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not list it, so the live FMA probe is reported beside it)
 
 
+def _dct_batch(n, seed):
+    from dctfhe.synthetic import synthetic_dct_batch
+    return synthetic_dct_batch(n, seed=seed)
+
+
+def _rgb_batch(n, seed):
+    from dctfhe import frontend, synthetic
+    tf = frontend.rgb_eval_transform(32)
+    return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed)]).astype(np.float32)
+
+
+# name -> (model factory name, in_channels, img_size, input batch maker, description)
+CONFIGS = {
+    "r20_24_16": ("ResNet20QAT", 24, 16, _dct_batch, "ResNet-20 24x16^2 DCT CIFAR-10 trunk (BASELINE config #2 shape)"),
+    "r20_3_32": ("ResNet20QAT", 3, 32, _rgb_batch, "ResNet-20 3x32^2 RGB CIFAR-10 trunk (BASELINE config #3)"),
+    "r18_3_32": ("ResNet18QAT", 3, 32, _rgb_batch, "ResNet-18 3x32^2 RGB CIFAR-10 trunk (BASELINE config #4 shape)"),
+}
+
+
 def measured_hbm_traffic(kernel_tag, cts_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/pmc_summary.py; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected inside this run).  Scaled by ciphertexts per
@@ -102,6 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="r20_24_16", choices=sorted(CONFIGS), help="BASELINE.json config; the metric is quoted on r20_24_16")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,8 +140,9 @@ def main():
 
     B = args.batch_per_gpu
     # same circuit and same keys on every rank (seed-regenerated: no key traffic)
-    calib = synthetic_dct_batch(100, seed=7)
-    model = models.ResNet20QAT(bit_width=4, in_channels=24, img_size=16, seed=0)
+    factory, in_ch, img, make_batch, workload = CONFIGS[args.config]
+    calib = make_batch(100, 7)
+    model = getattr(models, factory)(bit_width=4, in_channels=in_ch, img_size=img, seed=0)
     qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=6, p_error=0.01, device=local_rank)
     t0 = time.time()
     qm.fhe_circuit.keygen(seed=1)
@@ -130,7 +151,7 @@ def main():
 
     # this rank's shard of the global synthetic batch: image i -> rank i % world
     from dctfhe.sharding import gather_in_image_order, shard_indices
-    x_all = synthetic_dct_batch(B * world, seed=42)
+    x_all = make_batch(B * world, 42)
     x = x_all[shard_indices(B * world, rank, world)]
     q = qm.quantize_input(x)
     phases = qm.encode_input(q)
@@ -197,7 +218,7 @@ def main():
         achieved_gbs = alg_bytes / avg_launch_s / 1e9
         achieved_tf = flops_per_pbs * cts_per_launch / avg_launch_s / 1e12
         res = {
-            "metric": "encrypted images/sec, ResNet-20 DCT-24x16^2 CIFAR-10",
+            "metric": "encrypted images/sec, ResNet-20 DCT-24x16^2 CIFAR-10" if args.config == "r20_24_16" else f"encrypted images/sec, {args.config}",
             "value": value,
             "unit": "images/s",
             "n_gpus": world,
@@ -209,7 +230,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 torus + f64 FFT",
             "data": "synthetic",
-            "config": {"workload": f"ResNet-20 24x16^2 DCT CIFAR-10 trunk (BASELINE config #2 shape), {B} encrypted image(s) per GPU, "
+            "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU, "
                                    "exact-evaluation tiers, rounding_threshold_bits=6, n_bits=5, bit_width=4",
                        "images_per_gpu": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
                        "s_per_image_per_gpu": elapsed / (B * args.steps),
