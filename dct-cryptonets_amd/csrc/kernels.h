@@ -354,7 +354,7 @@ struct pbs_launch {
 };
 
 template <int LOGN, int K, int L, int P, int GROUPS>
-__global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P>::T * GROUPS), ((pbs_geom<LOGN, K, L, P>::T * GROUPS) >= 512 ? 1 : 2))
+__global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P>::T * GROUPS), ((P >= 16 || (pbs_geom<LOGN, K, L, P>::T * GROUPS) >= 512) ? 1 : 2))
 pbs_kernel(pbs_launch a) {
   using G = pbs_geom<LOGN, K, L, P>;
   constexpr int T = G::T;

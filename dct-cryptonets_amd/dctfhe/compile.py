@@ -353,7 +353,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
         z = bld.add(u, v)                                                    # backbone.py:102
         zr = np.maximum(z.q * s_c, 0)
         s_r2 = act_scale(zr, False, bits)
-        a = bld.lut(z, lambda vals, c=s_c, s=s_r2: act_quant(np.maximum(vals * c, 0), s, False, bits), False, False, s_r2, f"block{bi}: relu2")
+        a = bld.lut_to_conv(z, lambda vals, c=s_c, s=s_r2: act_quant(np.maximum(vals * c, 0), s, False, bits), False, False, s_r2, f"block{bi}: relu2")
 
     # AvgPool2d(k) as a window sum, then QuantIdentity (s4)                  backbone.py:276-278
     K = model.avgpool_kernel

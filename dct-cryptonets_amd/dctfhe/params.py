@@ -128,8 +128,10 @@ def default_params():
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
     t4r = TierSpec("T4r", n=864, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
-    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 1, 6: 4}, bit_tier_coarse=5, refresh_min_w=6)
+    # T5a: one-level twin of T5; the 5-bit residual-sum table is split the same way (T5a + T4r ~0.9x of T5)
+    t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0)
+    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
+                    coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5)
 
 
 def test_params():
