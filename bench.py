@@ -157,7 +157,10 @@ def main():
     phases = qm.encode_input(q)
     sess = qm._session("execute", B)
     cts = qm._keys.encrypt(phases.reshape(-1), 1000 + rank)
+    t_up = time.time()
     sess.upload(cts)                      # inputs resident in HBM before the timed region
+    upload_s = time.time() - t_up         # host -> device copy of the encrypted batch (reported, never part of `value`)
+    input_bytes = cts.nbytes
     del cts
 
     def sync():
@@ -237,6 +240,8 @@ def main():
                        "pbs_per_image": int(sum(stats.pbs_count)), "bit_steps_per_image": int(stats.bit_steps),
                        "table_lookups_per_image": int(stats.lut_sites), "conv_macs_per_image": int(stats.conv_macs),
                        "max_bit_width": int(stats.max_bit_width), "keygen_s": keygen_s,
+                       "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes),
+                       "images_per_s_pcie_inclusive": images / (elapsed + upload_s * args.steps),
                        "bit_exact_vs_integer_circuit": exact,
                        "predicted_labels": all_logits.argmax(dim=1).tolist(),
                        "expected_table_failures_per_image": qm.compiled.expected_failures_per_image},
