@@ -134,6 +134,25 @@ class CompiledCircuit:
         t = self.tensors[self.output_tensor]
         return t.C * t.H * t.W
 
+    def pbs_counts(self):
+        """{tier name: programmable bootstraps per image} -- table lookups on the site's table tier, rounding steps
+        on the bit tier (steps below coarse_from) or the one-level bit tier (steps from coarse_from on)."""
+        ps, out = self.param_set, {}
+        for o in self.ops:
+            if o.type != OP_LUT:
+                continue
+            s = self.tensors[o.src0]
+            n = s.C * s.H * s.W
+            out[ps.tiers[o.ip[4]].name] = out.get(ps.tiers[o.ip[4]].name, 0) + n
+            if o.r:
+                cf = o.ip[8] if (o.ip[7] >= 0 and o.ip[8] < o.r) else o.r
+                fine, coarse = min(cf, o.r), o.r - min(cf, o.r)
+                if fine:
+                    out[ps.tiers[o.ip[5]].name] = out.get(ps.tiers[o.ip[5]].name, 0) + n * fine
+                if coarse:
+                    out[ps.tiers[o.ip[7]].name] = out.get(ps.tiers[o.ip[7]].name, 0) + n * coarse
+        return out
+
     def report(self):
         """Text dump standing in for `fhe_circuit.mlir` (reference homomorphic_eval.py:309-311)."""
         names = {OP_CONV: "conv2d", OP_ADD: "add", OP_SUMPOOL: "sum_pool", OP_LUT: "round_lut"}

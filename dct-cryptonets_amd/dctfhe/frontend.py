@@ -28,6 +28,8 @@ SUBSET_DEFAULT = {
     24: ([0, 1, 2, 3, 4, 5, 8, 9, 10, 16, 17, 18, 24, 32], [0, 1, 3, 8, 24], [0, 1, 3, 8, 24]),
     48: ([0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28, 29, 32, 33, 34, 35, 40, 41, 42, 43],
          [0, 1, 2, 8, 9, 10, 16, 17], [0, 1, 2, 8, 9, 10, 16, 17]),
+    64: ([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28, 29, 32, 33, 34, 35, 36, 37,
+          40, 41, 42, 43, 44, 45, 48, 49, 50, 51, 52, 53], [0, 1, 2, 8, 9, 10, 16, 17, 24, 25], [0, 1, 2, 8, 9, 10, 16, 17, 24, 25]),
 }
 
 
@@ -142,10 +144,45 @@ def transform_dct_size(img, size):
     return matrix2dct(y, size), matrix2dct(slot_cb, size), matrix2dct(slot_cr, size)
 
 
+def _round_half_away(x):
+    return np.sign(x) * np.floor(np.abs(x) + 0.5)
+
+
+def transform_dct_jpeg(img):
+    """8x8 path of the reference (cvfunctional.py:21-26): TurboJPEG.encode(img, quality=100, jpeg_subsample=2) then
+    jpeg2dct.loads -> QUANTISED coefficients.  Restated from the JPEG/libjpeg definitions [K] -- PARITY UNPINNED, neither
+    library is available:
+      * the encoder's default pixel format is BGR while the array is RGB, so red and blue trade places inside the JPEG;
+      * JFIF full-range YCbCr (libjpeg jccolor, 16-bit fixed point, rounded);
+      * 4:2:0: 2x2 box average with libjpeg's alternating bias 1,2,1,2 (h2v2_downsample);
+      * level shift -128, orthonormal 8x8 DCT-II (the JPEG DCT), quantisation by the quality-100 tables = all ones,
+        rounded half away from zero (libjpeg's quantiser); natural (row-major) coefficient order within a block.
+    libjpeg's integer DCT (jfdctint) may differ from this float DCT by one unit on rounding ties.
+    Returns (dct_y [H/8, W/8, 64], dct_cb [H/16, W/16, 64], dct_cr [H/16, W/16, 64]) as float64 holding integers."""
+    h, w = (img.shape[0] // 16) * 16, (img.shape[1] // 16) * 16
+    if (h, w) != img.shape[:2]:
+        raise ValueError("image sides must be multiples of 16 (the reference crops to 8*S)")
+    r, g, b = [img[..., i].astype(np.int64) for i in (2, 1, 0)]                 # array handed over as if it were BGR
+    fix = lambda c: int(round(c * 65536))
+    half = 32768
+    y = (fix(0.29900) * r + fix(0.58700) * g + fix(0.11400) * b + half) >> 16
+    cb = (-fix(0.16874) * r - fix(0.33126) * g + fix(0.50000) * b + (128 << 16) + half - 1) >> 16
+    cr = (fix(0.50000) * r - fix(0.41869) * g - fix(0.08131) * b + (128 << 16) + half - 1) >> 16
+
+    def down(p):
+        bias = np.arange(p.shape[1] // 2) % 2 + 1                                # libjpeg: bias = 1; ...; bias ^= 3
+        return (p[0::2, 0::2] + p[0::2, 1::2] + p[1::2, 0::2] + p[1::2, 1::2] + bias[None, :]) >> 2
+
+    planes = [np.clip(y, 0, 255), down(np.clip(cb, 0, 255)), down(np.clip(cr, 0, 255))]
+    out = []
+    for pl in planes:
+        out.append(_round_half_away(matrix2dct(pl.astype(np.uint8), 8)))
+    return out[0], out[1], out[2]
+
+
 def dct_eval_transform(filter_size=4, image_size_dct=16, channels=24, dct_pattern="default"):
-    """The composed evaluation transform of reference datamgr.py:192-219 for the matrix2dct path."""
-    if filter_size == 8:
-        raise NotImplementedError("the 8x8 path is JPEG-domain (TurboJPEG q=100 + jpeg2dct): SURVEY 8(f) rank 3")
+    """The composed evaluation transform of reference datamgr.py:192-219 (matrix2dct path for filter 4, JPEG-domain
+    path for filter 8)."""
     S = image_size_dct
 
     def tf(img_u8):
@@ -157,8 +194,11 @@ def dct_eval_transform(filter_size=4, image_size_dct=16, channels=24, dct_patter
             oh, ow = side, int(side * w / h)
         x = resize_u8(img_u8, oh, ow)
         x = center_crop(x, filter_size * S)
-        dy, dcb, dcr = transform_dct_size(x, filter_size)
-        up = lambda d: d if d.shape[:2] == (S, S) else _bilinear(d, S, S)     # UpScaleDCT, cvtransforms.py:56-64
+        dy, dcb, dcr = transform_dct_jpeg(x) if filter_size == 8 else transform_dct_size(x, filter_size)
+        # UpScaleDCT, cvtransforms.py:56-64.  The JPEG path hands int16 planes to cv2.resize, which rounds the
+        # interpolated value back to int16 (cvRound = half to even) [K]; the matrix2dct path stays float.
+        rnd = np.rint if filter_size == 8 else (lambda a: a)
+        up = lambda d: d if d.shape[:2] == (S, S) else rnd(_bilinear(d, S, S))
         planes = [np.ascontiguousarray(up(d).transpose(2, 0, 1)).astype(np.float32) for d in (dy, dcb, dcr)]   # ToTensorDCT
         return subset_aggregate_normalize(*planes, channels=channels, pattern=dct_pattern, filter_size=filter_size)
 

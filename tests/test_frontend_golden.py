@@ -63,3 +63,38 @@ def test_full_transform_self_consistency():
     y, cr, cb = frontend.rgb_to_ycrcb_u8(flat)
     assert (y == 128).all() and (cr == 128).all() and (cb == 128).all()
     assert np.array_equal(frontend.halve_u8(np.array([[1, 2], [3, 4]], np.uint8)), [[3]])
+
+
+def test_jpeg_domain_dct_self_consistency():
+    """8x8 path (reference cvfunctional.py:21-26) -- PARITY UNPINNED (TurboJPEG / jpeg2dct absent): checks the JPEG
+    definitions the restatement follows, not the libraries."""
+    from dctfhe import frontend
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    y, cb, cr = frontend.transform_dct_jpeg(img)
+    assert y.shape == (4, 6, 64) and cb.shape == (2, 3, 64) and cr.shape == (2, 3, 64)
+    assert np.array_equal(y, np.round(y)) and np.abs(y).max() <= 1024
+    # a flat grey image: only DC, luma DC = 8 * (Y - 128), chroma DC = 0 (Cb = Cr = 128)
+    flat = np.full((16, 16, 3), 200, np.uint8)
+    fy, fcb, fcr = frontend.transform_dct_jpeg(flat)
+    assert fy[0, 0, 0] == 8 * (200 - 128) and not fy[..., 1:].any() and not fcb.any() and not fcr.any()
+    # the encoder reads the RGB array as BGR: a pure "red" array is blue inside the JPEG -> Cb high, Cr low
+    red = np.zeros((16, 16, 3), np.uint8); red[..., 0] = 255
+    _, rcb, rcr = frontend.transform_dct_jpeg(red)
+    assert rcb[0, 0, 0] > 0 > rcr[0, 0, 0]
+    # inverse DCT of the quantised coefficients reproduces the luma plane within the rounding of 64 coefficients
+    T = np.array([[1 / np.sqrt(8) if i == 0 else np.sqrt(2 / 8) * np.cos((2 * j + 1) * i * np.pi / 16) for j in range(8)] for i in range(8)])
+    r, g, b = [img[..., i].astype(np.int64) for i in (2, 1, 0)]
+    luma = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16
+    rec = np.einsum("ij,abjk,kl->abil", T.T, y.reshape(4, 6, 8, 8), T) + 128
+    assert np.abs(rec.transpose(0, 2, 1, 3).reshape(32, 48) - luma).max() < 4.0
+    with pytest.raises(ValueError):
+        frontend.transform_dct_jpeg(np.zeros((20, 16, 3), np.uint8))
+
+
+def test_filter8_eval_transform_shapes():
+    from dctfhe import frontend
+    img = np.random.default_rng(2).integers(0, 256, (300, 260, 3), dtype=np.uint8)
+    for ch in (48, 64):
+        x = frontend.dct_eval_transform(filter_size=8, image_size_dct=14, channels=ch)(img)
+        assert x.shape == (ch, 14, 14) and x.dtype == np.float32 and np.isfinite(x).all()
