@@ -224,7 +224,8 @@ static int check_params(const dctfhe_params* p) {
     const dctfhe_tier& t = p->tiers[i];
     if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
     if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
-    if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || (t.l >= 2 && t.beta > 16)) return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2)", i);
+    if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 31))
+      return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 31 when l == 1)", i);
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);

@@ -27,6 +27,17 @@
 #define HD inline __attribute__((always_inline))
 #endif
 
+#ifndef DCTFHE_SHARED_TWIDDLES
+#define DCTFHE_SHARED_TWIDDLES 1
+#endif
+
+// pinning the interleaved order with scheduling barriers measured 8% slower than leaving hipcc free (N = 8192)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PIN_FFT_ORDER)
+#define DCTFHE_FFT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DCTFHE_FFT_SCHED_BARRIER() ((void)0)
+#endif
+
 namespace dctfhe {
 
 struct cplx { double re, im; };
@@ -173,7 +184,9 @@ HD int pass_addr(int t, int j) {
 // Forward transform of one polynomial.
 //   v[0..P)   in : folded, UN-twisted points z_n = x_n + i x_{n+M} for n = t + T*j
 //             out: spectrum points at in-place addresses pass_addr<S-1>(t, j)
-//   tw        : table of G::TW_ELEMS entries: pass twiddles, then T twist bases e^{i pi t/N}
+//   tw        : table of G::TW_ELEMS entries: pass twiddles (the first G::TW_TOTAL, all the transform reads), then
+//               the T twist bases e^{i pi t/N};  twist = entry TW_TOTAL + t, handed over by value so that a kernel
+//               short of LDS can keep only the pass twiddles there
 //   exch      : LDS exchange buffer (G::EXCH_ELEMS), shared by the T threads of this polynomial
 //   sync      : barrier for those T threads (see the barrier discipline inside).
 // The exchange between pass i and i+1 only moves points among groups of W_i consecutive threads
@@ -185,7 +198,7 @@ struct no_hook { HD void operator()() const {} };
 // `before_last` runs right after the last gather, before the last pass's butterflies: the caller uses it to put
 // its key loads in flight under that pass.
 template <int LOGM, int P, class Sync, class WSync, class Hook = no_hook>
-HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync, Hook&& before_last = Hook{}) {
+HD void fft_forward(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync, Hook&& before_last = Hook{}) {
 #if defined(DCTFHE_ABLATE_FFT)   // timing experiments only
   return;
 #endif
@@ -210,7 +223,7 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
       // twiddle powers by a running product: two live values instead of R (the tree of squarings cost 24 more
       // registers and measured no better noise: tests/emul/fftnoise.cpp)
       {
-        cplx run = (i == 0) ? tw[G::TW_TOTAL + t] : cmk(1.0, 0.0);
+        cplx run = (i == 0) ? twist : cmk(1.0, 0.0);
         if constexpr (i == 0) y[0] = cmul(y[0], run);
         static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); y[k] = cmul(y[k], run); });
       }
@@ -232,7 +245,7 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
 // Inverse transform (unnormalised; the 1/M lives in the Fourier key).
 //   v[0..P)   in : spectrum at addresses pass_addr<S-1>(t, j);  out: z_n for n = t + T*j, twist removed.
 template <int LOGM, int P, class Sync, class WSync>
-HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
+HD void fft_inverse(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync) {
 #if defined(DCTFHE_ABLATE_FFT)
   return;
 #endif
@@ -245,7 +258,7 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
     if constexpr (i < S - 1) {
       const cplx b = tw[G::tw_offset(i) + (t % W)];
       {
-        cplx run = (i == 0) ? tw[G::TW_TOTAL + t] : cmk(1.0, 0.0);
+        cplx run = (i == 0) ? twist : cmk(1.0, 0.0);
         if constexpr (i == 0) v[0] = cmulc(v[0], run);
         static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); v[k] = cmulc(v[k], run); });
       }
@@ -269,6 +282,167 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, cplx* exch, Sync&& sync, WSy
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// NP transforms of independent polynomials, interleaved pass by pass: polynomial u exchanges through its own
+// buffer exch + u * G::EXCH_ELEMS.  While the LDS unit drains the scatter of polynomial u the VALU runs the
+// butterflies of polynomial u+1, and the butterflies of polynomial u start as soon as ITS gather has landed
+// while the gather of u+1 is still in flight (the LDS queue of a wave returns in order, so the compiler can wait
+// on a partial count).  One barrier pair per pass serves all NP polynomials.  Same arithmetic per polynomial,
+// in the same order, as fft_forward / fft_inverse: results are bit-identical to NP separate calls.
+template <int LOGM, int P, int NP, class Sync, class WSync>
+HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync) {
+#if defined(DCTFHE_ABLATE_FFT)
+  return;
+#endif
+  using G = fft_geom<LOGM, P>;
+  constexpr int S = G::S;
+  static_for<0, NP>([&](auto U) {
+    constexpr int u = decltype(U)::value;
+    static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = mul_root64<j*(64 / (4 * P)), +1>(v[u][j]); });
+  });
+  static_for<0, S>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int R = G::radix(i);
+    constexpr int W = G::weight(i);
+    if constexpr (i < S - 1) {
+      const cplx b = tw[G::tw_offset(i) + (t % W)];
+      const cplx run0 = (i == 0) ? twist : cmk(1.0, 0.0);
+      if constexpr (W <= 64) wsync(); else sync();      // nobody still gathers from the buffers about to be written
+#if DCTFHE_SHARED_TWIDDLES
+      // butterflies of all NP polynomials, then ONE running twiddle product applied to all of them (the chain costs
+      // as much as applying it: 4 f64 instructions per step), then the scatters
+      cplx y[NP][P];
+      static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; small_dft<P, 1, -1>::run(v[u], y[u]); });
+      {
+        cplx run = run0;
+        if constexpr (i == 0) static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; y[u][0] = cmul(y[u][0], run); });
+        static_for<1, R>([&](auto K) {
+          constexpr int k = decltype(K)::value;
+          run = cmul(run, b);
+          static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; y[u][k] = cmul(y[u][k], run); });
+        });
+      }
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        cplx* ex = exch + u * G::EXCH_ELEMS;
+#if defined(DCTFHE_ABLATE_EXCH)
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[u][(j + 1) % P]; });
+#else
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[u][j]; });
+#endif
+      });
+#else
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        cplx y[P];
+        small_dft<P, 1, -1>::run(v[u], y);
+        cplx run = run0;
+        if constexpr (i == 0) y[0] = cmul(y[0], run);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); y[k] = cmul(y[k], run); });
+        cplx* ex = exch + u * G::EXCH_ELEMS;
+#if defined(DCTFHE_ABLATE_EXCH)   // timing experiments only: no LDS traffic, wrong results
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[(j + 1) % P]; });
+#else
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+#endif
+        DCTFHE_FFT_SCHED_BARRIER();
+      });
+#endif
+      if constexpr (W <= 64) wsync(); else sync();
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const cplx* ex = exch + u * G::EXCH_ELEMS;
+#if !defined(DCTFHE_ABLATE_EXCH)
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
+#endif
+      });
+      DCTFHE_FFT_SCHED_BARRIER();
+    } else {
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        cplx y[P];
+        if constexpr (R == P) {
+          small_dft<P, 1, -1>::run(v[u], y);
+        } else {
+          static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, -1>::run(v[u] + g * R, y + g * R); });
+        }
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[j]; });
+        DCTFHE_FFT_SCHED_BARRIER();
+      });
+    }
+  });
+}
+
+template <int LOGM, int P, int NP, class Sync, class WSync>
+HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync) {
+#if defined(DCTFHE_ABLATE_FFT)
+  return;
+#endif
+  using G = fft_geom<LOGM, P>;
+  constexpr int S = G::S;
+  static_for<0, S>([&](auto Irev) {
+    constexpr int i = S - 1 - decltype(Irev)::value;
+    constexpr int R = G::radix(i);
+    constexpr int W = G::weight(i);
+    cplx b = cmk(1.0, 0.0), run0 = cmk(1.0, 0.0);
+    if constexpr (i < S - 1) {
+      b = tw[G::tw_offset(i) + (t % W)];
+      if constexpr (i == 0) run0 = twist;
+    }
+#if DCTFHE_SHARED_TWIDDLES
+    if constexpr (i < S - 1) {
+      cplx run = run0;
+      if constexpr (i == 0) static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; v[u][0] = cmulc(v[u][0], run); });
+      static_for<1, R>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        run = cmul(run, b);
+        static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; v[u][k] = cmulc(v[u][k], run); });
+      });
+    }
+#endif
+    static_for<0, NP>([&](auto U) {
+      constexpr int u = decltype(U)::value;
+#if !DCTFHE_SHARED_TWIDDLES
+      if constexpr (i < S - 1) {
+        cplx run = run0;
+        if constexpr (i == 0) v[u][0] = cmulc(v[u][0], run);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); v[u][k] = cmulc(v[u][k], run); });
+      }
+#endif
+      cplx y[P];
+      if constexpr (R == P) {
+        small_dft<P, 1, +1>::run(v[u], y);
+      } else {
+        static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v[u] + g * R, y + g * R); });
+      }
+      if constexpr (i > 0) {
+        cplx* ex = exch + u * G::EXCH_ELEMS;
+#if defined(DCTFHE_ABLATE_EXCH)
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[(j + 1) % P]; });
+#else
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+#endif
+      } else {
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = mul_root64<j*(64 / (4 * P)), -1>(y[j]); });
+      }
+      DCTFHE_FFT_SCHED_BARRIER();
+    });
+    if constexpr (i > 0) {
+      constexpr int Wp = G::weight(i - 1);
+      if constexpr (Wp <= 64) wsync(); else sync();
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const cplx* ex = exch + u * G::EXCH_ELEMS;
+#if !defined(DCTFHE_ABLATE_EXCH)
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
+#endif
+      });
+      if constexpr (Wp <= 64) wsync(); else sync();
+      DCTFHE_FFT_SCHED_BARRIER();
+    }
+  });
+}
+
 // host-side fill of the twiddle table (G::TW_ELEMS entries)
 template <int LOGM, int P>
 inline void fill_twiddles(cplx* tw) {
@@ -287,12 +461,17 @@ inline void fill_twiddles(cplx* tw) {
   }
 }
 
-// double -> torus (mod 2^64), exact for |d| < 2^116
+// double -> torus: the integer nearest to d, mod 2^64; exact for |d| < 2^116.
+// Split d = hi * 2^32 + lo with hi = rint(d / 2^32): lo and (hi mod 2^32) both lie in [-2^31, 2^31] and are exact in
+// f64, so adding 1.5 * 2^52 leaves their two's-complement value in the low mantissa bits -- no f64 -> i64 conversion
+// (which gfx950 expands to six f64 instructions) and no compare/select.  8 f64 + 2 integer instructions.
 HD uint64_t f64_to_torus(double d) {
-  const double q = __builtin_rint(d * 5.421010862427522170037e-20);  // 2^-64
-  double r = __builtin_fma(-q, 18446744073709551616.0, d);           // in [-2^63, 2^63]
-  if (r >= 9223372036854775808.0) r -= 18446744073709551616.0;
-  return (uint64_t)(int64_t)r;
+  const double hi = __builtin_rint(d * 2.3283064365386962890625e-10);                                   // 2^-32
+  const double lo = __builtin_fma(-hi, 4294967296.0, d);
+  const double h2 = __builtin_fma(-__builtin_rint(hi * 2.3283064365386962890625e-10), 4294967296.0, hi);
+  const double MAGIC = 6755399441055744.0;                                                              // 1.5 * 2^52
+  const uint64_t bl = __builtin_bit_cast(uint64_t, lo + MAGIC), bh = __builtin_bit_cast(uint64_t, h2 + MAGIC);
+  return (bl - 0x4338000000000000ULL) + (bh << 32);
 }
 
 }  // namespace dctfhe

@@ -361,7 +361,7 @@ pbs_kernel(pbs_launch a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cplx* tw = reinterpret_cast<cplx*>(smem_raw);
   unsigned char* per_group = smem_raw + G::TW_BYTES;
-  for (int x = threadIdx.x; x < G::F::TW_ELEMS; x += blockDim.x) tw[x] = a.tw[x];
+  for (int x = threadIdx.x; x < G::TW_LDS_ELEMS; x += blockDim.x) tw[x] = a.tw[x];
   __syncthreads();
 #if defined(DCTFHE_STAGGER)   // experiment: desynchronise co-resident workgroups by half a transform
   if ((blockIdx.x >> 8) & 1) for (int z = 0; z < DCTFHE_STAGGER; z++) __builtin_amdgcn_s_sleep(64);
@@ -374,7 +374,7 @@ pbs_kernel(pbs_launch a) {
   cplx* exch = reinterpret_cast<cplx*>(mine);
   uint64_t* stage = reinterpret_cast<uint64_t*>(mine + G::STAGE_OFFSET);     // aliases the exchange buffer when G::ALIAS
   uint64_t* accl = reinterpret_cast<uint64_t*>(mine + G::SHARED_BYTES);
-  uint32_t* pf_dump = reinterpret_cast<uint32_t*>(mine + G::SHARED_BYTES + G::ACCL_BYTES);
+  uint32_t* pf_dump = nullptr;     // host emulation only
   pbs_args A;
   A.ct_small = a.cts_small + e * (size_t)(a.n + 1);
   A.n = a.n; A.beta = a.beta; A.bsk = a.bsk;
@@ -388,6 +388,7 @@ pbs_kernel(pbs_launch a) {
   A.body_add = a.body_add;
   A.bsk_wrap = a.bsk_wrap;
   A.pf_parts = a.pf_parts;
+  if constexpr (G::TWIST_LDS) A.twist = tw + G::F::TW_TOTAL; else A.twist = a.tw + G::F::TW_TOTAL;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
   if constexpr (T <= 64) {
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS

@@ -34,6 +34,10 @@ namespace dctfhe {
 #define PBS_KEY_BATCH 4
 #endif
 
+#ifndef PBS_PAIR
+#define PBS_PAIR 1
+#endif
+
 #ifndef PBS_PF_DIST
 #define PBS_PF_DIST 2
 #endif
@@ -52,35 +56,49 @@ struct pbs_geom {
   // accumulator polynomials live in LDS instead of registers (32 VGPRs each at P = 8).
   // measured (profiles/r01_exp_lds_acc.log): +11..13% where the register arrays spilled (k = 2, or three levels),
   // -2..3% where they did not (one level, k = 1) -- hence the rule.  The body polynomial K always stays in registers.
+  // PAIR: the K+1 = 2 forward transforms of a one-level k = 1 bootstrap run interleaved (fft_forward_n), and so do
+  // the two inverse ones: LDS scatter/gather of one polynomial overlaps the butterflies of the other, and the
+  // barrier count per CMUX drops from 11 to 6.  Costs a second exchange buffer; the rotation stages alias the two.
+  static constexpr bool PAIR = PBS_PAIR && K == 1 && L == 1;
   static constexpr int NL_AUTO = (K >= 2 || L >= 3) ? 1 : 0;
   static constexpr int NL = PBS_LDS_POLYS < 0 ? NL_AUTO : (PBS_LDS_POLYS < K ? PBS_LDS_POLYS : K);
   static constexpr int STAGE_BYTES = N * 8;
   static constexpr int EXCH_BYTES = F::EXCH_ELEMS * 16;
   // the stage only aliases the exchange buffer when an LDS-resident polynomial needs the room: aliasing costs one
   // extra barrier per register polynomial and iteration (measured -3% on the one-level N = 8192 kernel)
-  static constexpr bool ALIAS = NL > 0;
+  static constexpr bool ALIAS = NL > 0 || PAIR;
+  static_assert(!PAIR || (NL == 0 && EXCH_BYTES >= STAGE_BYTES), "pair mode stages each polynomial in its exchange buffer");
   static constexpr int STAGE_OFFSET = ALIAS ? 0 : EXCH_BYTES;
-  static constexpr int SHARED_BYTES = ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
+  static constexpr int SHARED_BYTES = PAIR ? 2 * EXCH_BYTES : ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
   static constexpr int ACCL_BYTES = NL * N * 8;
-  static constexpr int GROUP_BYTES = SHARED_BYTES + ACCL_BYTES + T * 4;   // + L2 warm-up sink
-  static constexpr int TW_BYTES = F::TW_ELEMS * 16;  // shared by all groups of a workgroup
+  static constexpr int GROUP_BYTES = SHARED_BYTES + ACCL_BYTES;
+  // twiddle table in LDS, shared by all groups of a workgroup; the pair kernels of the two big rings are short of
+  // LDS and leave the T twist bases in global memory (read once per bootstrap)
+  static constexpr bool TWIST_LDS = !(PAIR && LOGN >= 12);
+  static constexpr int TW_LDS_ELEMS = TWIST_LDS ? F::TW_ELEMS : F::TW_TOTAL;
+  static constexpr int TW_BYTES = TW_LDS_ELEMS * 16;
 };
 
-// signed gadget decomposition, closest-representable rounding; digs[lev], lev 0 most significant
+// signed gadget decomposition, closest-representable rounding; digs[lev], lev 0 most significant, digits in [-B/2, B/2).
+// Carries come out of one addition: with B/2 added at every digit position the plain base-B digits minus B/2 are the
+// balanced ones (the balanced representation is unique mod B^L).  One level is the arithmetic shift of the rounded
+// high word.
 template <int L>
 HD void decompose(uint64_t v, int beta, int32_t* digs) {
-  const int total = L * beta;
-  uint64_t x = (v + (1ULL << (63 - total))) >> (64 - total);
-  const uint64_t B = 1ULL << beta, half = B >> 1, mask = B - 1;
-  uint64_t carry = 0;
-  static_for<0, L>([&](auto Lv) {
-    constexpr int lev = L - 1 - decltype(Lv)::value;
-    uint64_t d = (x & mask) + carry;
-    x >>= beta;
-    const bool hi = d >= half;
-    digs[lev] = (int32_t)((int64_t)d - (hi ? (int64_t)B : 0));
-    carry = hi ? 1 : 0;
-  });
+  if constexpr (L == 1) {
+    const uint32_t hi = (uint32_t)(v >> 32) + (1u << (31 - beta));      // beta <= 31: rounding touches the high word only
+    digs[0] = (int32_t)hi >> (32 - beta);
+  } else {
+    const int total = L * beta;
+    const uint64_t B = 1ULL << beta, half = B >> 1, mask = B - 1;
+    uint64_t offs = 0;
+    static_for<0, L>([&](auto Lv) { offs |= half << (beta * decltype(Lv)::value); });
+    const uint64_t x = ((v + (1ULL << (63 - total))) >> (64 - total)) + offs;
+    static_for<0, L>([&](auto Lv) {
+      constexpr int lev = decltype(Lv)::value;
+      digs[lev] = (int32_t)((x >> (beta * (L - 1 - lev))) & mask) - (int32_t)half;
+    });
+  }
 }
 
 // test-vector coefficient j (0 <= j < N) of the table T (2^w entries)
@@ -102,6 +120,7 @@ struct pbs_args {
   int accumulate;             // 0: out = extract(ACC) (mask beyond K*N zeroed); 1: out += extract(ACC)
   uint64_t body_add;          // added to the body word (accumulate mode: the "- v" of a bit step)
   int bsk_wrap;               // 0 = off; >0: key bit i reads BSK[i % bsk_wrap] (cache experiments only)
+  const cplx* twist;          // the T twist bases e^{i pi t/N} (entries TW_TOTAL.. of the twiddle table; LDS or global)
   int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
 };
 
@@ -112,6 +131,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
   constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
   const int n = A.n;
   const int msh = 64 - LOGN - 2;
+  const cplx twist = A.twist[t];
 
   // L2 warm-up geometry: this workgroup owns lines [pf_line0, pf_line0 + pf_per) of every key bit
   constexpr int PF_LINES = (int)(G::BSK_ELEMS_PER_KEYBIT * 16 / 128);
@@ -148,6 +168,55 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT;
     cplx out[K + 1][P];
+    if constexpr (G::PAIR) {
+      // both accumulator polynomials go through their stages at once (stage p = exchange buffer p; everybody is past
+      // the last gather of the previous inverse transforms: their trailing barrier), one barrier, then the rotated
+      // reads; the leading barrier of the forward transforms covers those reads.
+      constexpr int EX = G::F::EXCH_ELEMS * 2;   // u64 words per exchange buffer
+      static_for<0, 2>([&](auto Pp) {
+        constexpr int p = decltype(Pp)::value;
+        static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[p * EX + t + T * r] = acc[p][r]; });
+      });
+      sync();
+      cplx v[2][P];
+      static_for<0, 2>([&](auto Pp) {
+        constexpr int p = decltype(Pp)::value;
+        static_for<0, 2 * P>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
+          const uint64_t x = stage[p * EX + (src & (N - 1))];
+          const uint64_t m = (uint64_t)0 - (uint64_t)((src >> LOGN) & 1);      // all ones where the rotation wraps: -x = (x ^ m) - m
+          int32_t dg[1];
+          decompose<1>((x ^ m) - m - acc[p][r], A.beta, dg);
+          if constexpr (r < P) v[p][r].re = (double)dg[0]; else v[p][r - P].im = (double)dg[0];
+        });
+      });
+      fft_forward_n<G::LOGM, P, 2>(v, t, tw, twist, exch, sync, wsync);
+      constexpr int KB = (P > PBS_KEY_BATCH) ? PBS_KEY_BATCH : P;
+      static_for<0, 2>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        static_for<0, P / KB>([&](auto Hb) {
+          constexpr int j0 = decltype(Hb)::value * KB;
+          cplx k0[KB], k1[KB];
+          static_for<0, KB>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+#if defined(DCTFHE_ABLATE_BSK)
+            k0[j] = cmk(1.0 + j, 0.5 * q); k1[j] = cmk(0.5 * q, 1.0 + j);
+#else
+            k0[j] = bsk_i[(size_t)(0 * 2 + q) * M + (j0 + j) * T + t];
+            k1[j] = bsk_i[(size_t)(1 * 2 + q) * M + (j0 + j) * T + t];
+#endif
+          });
+          DCTFHE_SCHED_BARRIER();
+          static_for<0, KB>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            // same order of operations as the unpaired path: ((0 + v0 k0) + v1 k1)
+            out[q][j0 + j] = cfma(v[1][j0 + j], k1[j], cfma(v[0][j0 + j], k0[j], cmk(0.0, 0.0)));
+          });
+          DCTFHE_SCHED_BARRIER();
+        });
+      });
+    } else {
     static_for<0, K + 1>([&](auto Q) { static_for<0, P>([&](auto J) { out[decltype(Q)::value][decltype(J)::value] = cmk(0.0, 0.0); }); });
 
     static_for<0, K + 1>([&](auto Pp) {
@@ -173,7 +242,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         uint64_t x, own;
         if constexpr (p < NL) { x = accl[p * N + (src & (N - 1))]; own = accl[p * N + t + T * r]; }
         else                  { x = stage[src & (N - 1)]; own = acc[p][r]; }
-        if (src & N) x = (uint64_t)0 - x;
+        if (src & N) x = (uint64_t)0 - x;     // (a branch-free (x ^ m) - m here makes hipcc spill 200+ bytes more per lane)
         int32_t dg[L];
         decompose<L>(x - own, A.beta, dg);
         first[r] = (double)dg[0];
@@ -190,7 +259,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
           if constexpr (lev == 0) v[j] = cmk(first[j], first[P + j]);
           else v[j] = cmk((double)(int16_t)(packed[j] >> (16 * (lev - 1))), (double)(int16_t)(packed[P + j] >> (16 * (lev - 1))));
         });
-        fft_forward<G::LOGM, P>(v, t, tw, exch, sync, wsync);
+        fft_forward<G::LOGM, P>(v, t, tw, twist, exch, sync, wsync);
         const cplx* row = bsk_i + (size_t)(p * L + lev) * (K + 1) * M;
         // Key loads are issued as one batch per output polynomial and only then consumed: left to itself hipcc
         // (at this register pressure) emits load; s_waitcnt vmcnt(0); fma -- 16 serialized L2 round trips per row
@@ -217,6 +286,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         });
       });
     });
+    }  // !PAIR
 
     // L2 warm-up.  Every CU walks the same key in near lock-step, so without help each key line is an HBM
     // miss that all CUs of the XCD wait on together (measured: 128 ms -> 94 ms per launch with the key
@@ -227,13 +297,18 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
        // arrays to scratch (2.4 KB/lane).  The key buffer carries PBS_PF_DIST zero key bits of padding at its end.
       uint32_t acc_pf = 0;
       static_for<0, PF_ROUNDS>([&](auto Rr) { acc_pf ^= *reinterpret_cast<const uint32_t*>(pf_ptr + (size_t)decltype(Rr)::value * T * 128); });
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(acc_pf));        // the touches only have to be issued
+#else
       pf_dump[t] = acc_pf;
+#endif
       pf_ptr += G::BSK_ELEMS_PER_KEYBIT * 16;
     }
 
+    if constexpr (G::PAIR) fft_inverse_n<G::LOGM, P, 2>(out, t, tw, twist, exch, sync, wsync);
     static_for<0, K + 1>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
-      fft_inverse<G::LOGM, P>(out[q], t, tw, exch, sync, wsync);
+      if constexpr (!G::PAIR) fft_inverse<G::LOGM, P>(out[q], t, tw, twist, exch, sync, wsync);
       static_for<0, P>([&](auto J) {
         constexpr int j = decltype(J)::value;
         if constexpr (q < NL) {
@@ -280,7 +355,7 @@ HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* 
     constexpr int j = decltype(J)::value;
     v[j] = cmk((double)(int64_t)poly[t + T * j], (double)(int64_t)poly[t + T * j + M]);
   });
-  fft_forward<LOGN - 1, P>(v, t, tw, exch, sync, wsync);
+  fft_forward<LOGN - 1, P>(v, t, tw, tw[F::TW_TOTAL + t], exch, sync, wsync);
   const double inv = 1.0 / (double)M;
   static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; dst[j * T + t] = cmk(v[j].re * inv, v[j].im * inv); });
 }

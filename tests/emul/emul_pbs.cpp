@@ -54,11 +54,12 @@ static int run_case(int n, int beta, int w, double sigma_bsk) {
       const size_t npoly = (size_t)n * rows * (K + 1);
       for (size_t q = 0; q < npoly; q++)
         key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), reinterpret_cast<cplx*>(shared.data()), sync, sync);
+      sync();   // on the device the key conversion is a separate kernel: nobody is still gathering when the bootstrap starts
       for (int c = 0; c < count; c++) {
         pbs_args A;
         A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data();
         A.table = table.data(); A.w = w; A.out = emu_out.data() + (size_t)c * (D + 1); A.D_out = D;
-        A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.pf_rank = 0;
+        A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = 0;
         pbs_thread<LOGN, K, L, P>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
         sync();
       }
@@ -105,9 +106,9 @@ static int fft_case() {
     auto sync = [&] { bar.arrive_and_wait(); };
     cplx v[P];
     for (int j = 0; j < P; j++) v[j] = cmk(x[t + T * j], x[t + T * j + M]);
-    fft_forward<LOGN - 1, P>(v, t, tw.data(), exch.data(), sync, sync);
+    fft_forward<LOGN - 1, P>(v, t, tw.data(), tw[F::TW_TOTAL + t], exch.data(), sync, sync);
     for (int j = 0; j < P; j++) spec[j * T + t] = v[j];
-    fft_inverse<LOGN - 1, P>(v, t, tw.data(), exch.data(), sync, sync);
+    fft_inverse<LOGN - 1, P>(v, t, tw.data(), tw[F::TW_TOTAL + t], exch.data(), sync, sync);
     for (int j = 0; j < P; j++) back[t + T * j] = v[j];
   };
   std::vector<std::thread> th;
@@ -147,6 +148,8 @@ int main() {
   fail |= run_case<9, 2, 1, 8>(16, 16, 3, 1e-13);
   fail |= run_case<9, 1, 3, 8>(16, 7, 4, 1e-12);
   fail |= run_case<10, 1, 2, 16>(12, 12, 4, 1e-13);
+  fail |= run_case<9, 1, 1, 8>(16, 20, 3, 1e-13);    // one level, k = 1: the pair-interleaved path
+  fail |= run_case<11, 1, 1, 8>(8, 22, 4, 1e-14);
   std::printf(fail ? "EMUL FAIL\n" : "EMUL OK\n");
   return fail;
 }

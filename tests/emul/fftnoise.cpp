@@ -39,9 +39,10 @@ void run(int n, int beta) {
     auto sync = [&] { bar.arrive_and_wait(); };
     const size_t npoly = (size_t)n * rows * (K + 1);
     for (size_t q = 0; q < npoly; q++) key_poly_to_fourier<LOGN, P>(bsk.data() + q * N, bsk_dev.data() + q * M, t, tw.data(), reinterpret_cast<cplx*>(shared.data()), sync, sync);
+    sync();
     for (int c = 0; c < count; c++) {
       pbs_args A; A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data(); A.table = table.data(); A.w = w;
-      A.out = o_emu.data() + (size_t)c * (D + 1); A.D_out = D; A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.pf_rank = 0;
+      A.out = o_emu.data() + (size_t)c * (D + 1); A.D_out = D; A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = 0;
       pbs_thread<LOGN, K, L, P>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync); sync();
     }
   };
