@@ -212,11 +212,15 @@ def main():
         avg_launch_s = pbs_ms[dom] * 1e-3 / max(launches, 1)
         cts_per_launch = cts_dom / max(launches, 1)
         N = td.N
-        bsk_bytes = td.n * td.l * (td.k + 1) ** 2 * N * 8.0
+        unroll = getattr(td, "unroll", 1)
+        bsk_bytes = (3 * td.n // 2 if unroll == 2 else td.n) * td.l * (td.k + 1) ** 2 * N * 8.0
         alg_bytes = cts_per_launch * ((td.n + 1) * 8.0 + (ps.D + 1) * 8.0) + bsk_bytes
         M = N / 2
         fft = 5.0 * M * math.log2(M)
-        flops_per_pbs = td.n * ((td.k + 1) * td.l * fft + (td.k + 1) * fft + (td.k + 1) ** 2 * td.l * M * 8.0)
+        if unroll == 2:   # two-bit blind rotation: per pair the same transforms, 3 key blocks folded with their monomials
+            flops_per_pbs = (td.n / 2) * ((td.k + 1) * td.l * fft + (td.k + 1) * fft + (td.k + 1) ** 2 * td.l * M * 30.0 + M * 18.0)
+        else:
+            flops_per_pbs = td.n * ((td.k + 1) * td.l * fft + (td.k + 1) * fft + (td.k + 1) ** 2 * td.l * M * 8.0)
         fp64_live = qm._ctx.fp64_peak()
         achieved_gbs = alg_bytes / avg_launch_s / 1e9
         achieved_tf = flops_per_pbs * cts_per_launch / avg_launch_s / 1e12

@@ -56,7 +56,9 @@ struct TierKeys {
   int8_t* d_kskT = nullptr;      // signed byte limbs, [8(n+1) padded to 128][D*lk], for the MFMA key switch
   int ncol_pad = 0;
   bool own_ksk = false;
-  cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]
+  cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]; unroll 2: [3n/2 blocks] for the pair secret
+  cplx* d_wtab = nullptr;        // unroll 2: e^{i pi m/N}, m < 2N, then e^{2 pi i k/8}, k < 8
+  uint8_t* d_spair = nullptr;    // unroll 2: derived secret (s1(1-s2), (1-s1)s2, s1 s2) per pair
   cplx* d_tw = nullptr;
 };
 
@@ -113,6 +115,9 @@ struct dctfhe_session {
   X(11, 1, 1, 8) X(11, 1, 2, 8) X(11, 1, 3, 8) X(12, 1, 1, 8) X(12, 1, 2, 8) X(12, 1, 3, 8)           \
   X(13, 1, 1, 8) X(13, 1, 2, 8) X(13, 1, 3, 8)
 
+// two-bit blind rotation (tier.unroll == 2): k = 1, one level
+#define PBS_MB_CASES(X) X(11) X(12) X(13)
+
 template <int LOGN, int K_, int L_, int P>
 constexpr int groups_for() {
   using G = pbs_geom<LOGN, K_, L_, P>;
@@ -132,7 +137,7 @@ static int tier_ppt(const dctfhe_tier& t) {
 static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st) {
   if (a.count == 0) return 0;
 #define X(LN, K_, L_, P_)                                                                            \
-  if (t.logN == LN && t.k == K_ && t.l == L_) {                                                      \
+  if (t.logN == LN && t.k == K_ && t.l == L_ && t.unroll == 1) {                                     \
     using G = pbs_geom<LN, K_, L_, P_>;                                                              \
     constexpr int GR = groups_for<LN, K_, L_, P_>();                                                 \
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                 \
@@ -147,6 +152,23 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
     return 0;                                                                                        \
   }
   PBS_CASES(X)
+#undef X
+#define X(LN)                                                                                        \
+  if (t.logN == LN && t.k == 1 && t.l == 1 && t.unroll == 2) {                                       \
+    using G = pbs_geom<LN, 1, 1, 8, 1>;                                                              \
+    constexpr int GR = groups_for<LN, 1, 1, 8>();                                                    \
+    const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                    \
+    static bool attr_done = false;                                                                   \
+    if (!attr_done) {                                                                                \
+      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, 1, 1, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr_done = true;                                                                              \
+    }                                                                                                \
+    const unsigned grid = (unsigned)((a.count + GR - 1) / GR);                                       \
+    hipLaunchKernelGGL((pbs_kernel<LN, 1, 1, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);   \
+    HIPCHK(hipGetLastError());                                                                       \
+    return 0;                                                                                        \
+  }
+  PBS_MB_CASES(X)
 #undef X
   return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d", t.logN, t.k, t.l);
 }
@@ -226,6 +248,8 @@ static int check_params(const dctfhe_params* p) {
     if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
     if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 31))
       return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 31 when l == 1)", i);
+    if (t.unroll != 1 && t.unroll != 2) return fail("tier %d: unroll must be 1 or 2", i);
+    if (t.unroll == 2 && (t.k != 1 || t.l != 1 || t.logN < 11 || (t.n & 1))) return fail("tier %d: unroll 2 needs k = 1, l = 1, N >= 2048, n even", i);
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);
@@ -245,7 +269,9 @@ static int gen_bsk_std_chunk(dctfhe_keys* K, int tier, int i0, int ni, uint64_t*
     HIPCHK(hipFuncSetAttribute((const void*)k_bsk_gen_std, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
     attr_done = true;
   }
-  hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, K->ctx->stream, K->d_s, K->d_S, i0, t.k, N,
+  // unroll 2: the "secret" is the pair secret of 3n/2 bits, i0/ni count its blocks
+  const uint8_t* bits = t.unroll == 2 ? K->tiers[tier].d_spair : K->d_s;
+  hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, K->ctx->stream, bits, K->d_S, i0, t.k, N,
                      t.l, t.beta, t.glwe_sigma, K->seed, (uint64_t)(STREAM_BSK_MASK + 2 * tier), d_out);
   HIPCHK(hipGetLastError());
   return 0;
@@ -297,14 +323,27 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
     HIPCHK(hipStreamSynchronize(st));
     const int N = 1 << t.logN, M = N / 2, rows = (t.k + 1) * t.l;
     const size_t per_bit_polys = (size_t)rows * (t.k + 1);
-    // PBS_PF_DIST extra (zero) key bits: the L2 warm-up of the last iterations reads past the key
-    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)(t.n + PBS_PF_DIST) * per_bit_polys * M * sizeof(cplx)));
-    HIPCHK(hipMemsetAsync(tk.d_bsk + (size_t)t.n * per_bit_polys * M, 0, (size_t)PBS_PF_DIST * per_bit_polys * M * sizeof(cplx), st));
-    const int chunk = std::max(1, (int)std::min<size_t>(t.n, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
+    const int blocks = t.unroll == 2 ? 3 * t.n / 2 : t.n;     // key-bit-sized blocks; blocks read per iteration: unroll 2 -> 3
+    const int pad = PBS_PF_DIST * (t.unroll == 2 ? 3 : 1);
+    if (t.unroll == 2) {
+      HIPCHK(hipMalloc(&tk.d_spair, (size_t)blocks));
+      hipLaunchKernelGGL(k_pair_secret, dim3((t.n / 2 + 255) / 256), dim3(256), 0, st, K->d_s, t.n, tk.d_spair);
+      std::vector<cplx> wt((size_t)2 * N + 8);
+      const long double PI = 3.141592653589793238462643383279502884L;
+      for (int m = 0; m < 2 * N; m++) { const long double a = PI * m / N; wt[m] = cmk((double)cosl(a), (double)sinl(a)); }
+      for (int m = 0; m < 8; m++) wt[(size_t)2 * N + m] = root64(8 * m);
+      HIPCHK(hipMalloc(&tk.d_wtab, wt.size() * sizeof(cplx)));
+      HIPCHK(hipMemcpyAsync(tk.d_wtab, wt.data(), wt.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    // extra (zero) key blocks: the L2 warm-up of the last iterations reads past the key
+    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)(blocks + pad) * per_bit_polys * M * sizeof(cplx)));
+    HIPCHK(hipMemsetAsync(tk.d_bsk + (size_t)blocks * per_bit_polys * M, 0, (size_t)pad * per_bit_polys * M * sizeof(cplx), st));
+    const int chunk = std::max(1, (int)std::min<size_t>(blocks, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
     uint64_t* d_std = nullptr;
     HIPCHK(hipMalloc(&d_std, (size_t)chunk * per_bit_polys * N * 8));
-    for (int i0 = 0; i0 < t.n; i0 += chunk) {
-      const int ni = std::min(chunk, t.n - i0);
+    for (int i0 = 0; i0 < blocks; i0 += chunk) {
+      const int ni = std::min(chunk, blocks - i0);
       CHK(gen_bsk_std_chunk(K, ti, i0, ni, d_std));
       CHK(launch_bsk_fourier(t, d_std, (size_t)ni * per_bit_polys, tk.d_tw, tk.d_bsk + (size_t)i0 * per_bit_polys * M, st));
     }
@@ -322,7 +361,7 @@ extern "C" int dctfhe_keys_destroy(dctfhe_keys* K) {
   hipFree(K->d_S); hipFree(K->d_s); hipFree(K->d_dummy);
   for (int i = 0; i < K->p.n_tiers; i++) {
     if (K->tiers[i].own_ksk) { hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); if (K->tiers[i].d_kskT) hipFree(K->tiers[i].d_kskT); }
-    hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw);
+    hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw); hipFree(K->tiers[i].d_wtab); hipFree(K->tiers[i].d_spair);
   }
   delete K;
   return 0;
@@ -346,10 +385,11 @@ extern "C" int dctfhe_keys_export_bsk(dctfhe_keys* K, int tier, uint64_t* out) {
   const dctfhe_tier& t = K->p.tiers[tier];
   HIPCHK(hipSetDevice(K->ctx->device));
   const int N = 1 << t.logN;
-  const size_t words = (size_t)t.n * (t.k + 1) * t.l * (t.k + 1) * N;
+  const int blocks = t.unroll == 2 ? 3 * t.n / 2 : t.n;     // unroll 2: the key of the pair secret
+  const size_t words = (size_t)blocks * (t.k + 1) * t.l * (t.k + 1) * N;
   uint64_t* d = nullptr;
   HIPCHK(hipMalloc(&d, words * 8));
-  CHK(gen_bsk_std_chunk(K, tier, 0, t.n, d));
+  CHK(gen_bsk_std_chunk(K, tier, 0, blocks, d));
   HIPCHK(hipStreamSynchronize(K->ctx->stream));
   HIPCHK(hipMemcpy(out, d, words * 8, hipMemcpyDeviceToHost));
   HIPCHK(hipFree(d));
@@ -435,7 +475,7 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
   const dctfhe_tier& t = K->p.tiers[tier];
   pbs_launch a;
   a.cts_small = d_small; a.count = count; a.n = t.n; a.beta = t.beta;
-  a.bsk = K->tiers[tier].d_bsk; a.tw = K->tiers[tier].d_tw;
+  a.bsk = K->tiers[tier].d_bsk; a.tw = K->tiers[tier].d_tw; a.wtab = K->tiers[tier].d_wtab;
   a.tables = d_tables; a.w = w; a.table_idx = d_idx; a.hw = hw; a.nchan = nchan; a.e_offset = e_offset;
   a.out = d_out; a.D_out = K->p.D; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy; a.bsk_wrap = 0; a.pf_parts = 16;
   const int h = tm ? tm->begin(tier) : -1;
@@ -646,11 +686,14 @@ extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, d
   auto tier_flops = [&](const dctfhe_tier& t) {
     const double N = (double)(1 << t.logN), M = N / 2;
     const double fft = 5.0 * M * std::log2(M);
+    if (t.unroll == 2)   // per PAIR of key bits: the same transforms, three key blocks folded with their monomials (22 + 8 flops per
+                         // point and key polynomial), the monomials themselves (18 per point)
+      return (t.n / 2) * ((t.k + 1) * t.l * fft + (t.k + 1) * fft + (double)(t.k + 1) * (t.k + 1) * t.l * M * 30.0 + M * 18.0);
     return t.n * ((t.k + 1) * t.l * fft + (t.k + 1) * fft + (double)(t.k + 1) * (t.k + 1) * t.l * M * 8.0);
   };
   auto key_bytes = [&](const dctfhe_tier& t) {
     const double N = (double)(1 << t.logN);
-    return (double)t.n * t.l * (t.k + 1) * (t.k + 1) * N * 8.0 + (double)P->D * t.lk * (t.n + 1) * 8.0;
+    return (double)(t.unroll == 2 ? 3 * t.n / 2 : t.n) * t.l * (t.k + 1) * (t.k + 1) * N * 8.0 + (double)P->D * t.lk * (t.n + 1) * 8.0;
   };
   for (const Op& o : c->ops) {
     const double ein = elems(o.src0), eout = elems(o.dst);

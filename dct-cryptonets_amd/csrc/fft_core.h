@@ -443,6 +443,20 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
   });
 }
 
+// Frequency index of in-place position p after fft_forward: the value there is the polynomial evaluated at
+// e^{i pi (1 - 4k) / N}.  Position digit i (weight W_i) holds frequency digit k_i, whose weight is R_0 * ... * R_{i-1}.
+// Thread t leaves register j at position P*t + j.
+template <int LOGM, int P>
+HD int spectrum_freq(int p) {
+  int k = 0, fw = 1;
+  for (int i = 0; i < geom_passes(LOGM, P); i++) {
+    const int W = geom_weight(LOGM, P, i), R = geom_radix(LOGM, P, i);
+    k += ((p / W) % R) * fw;
+    fw *= R;
+  }
+  return k;
+}
+
 // host-side fill of the twiddle table (G::TW_ELEMS entries)
 template <int LOGM, int P>
 inline void fill_twiddles(cplx* tw) {

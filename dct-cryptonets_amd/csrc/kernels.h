@@ -96,6 +96,14 @@ __global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restri
   }
 }
 
+// secret of the two-bit blind rotation: per pair (s1, s2) the three products s1(1-s2), (1-s1)s2, s1 s2
+__global__ void k_pair_secret(const uint8_t* __restrict__ s, int n, uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i + 1 >= n) return;
+  const uint8_t a = s[2 * i], b = s[2 * i + 1];
+  out[3 * i] = a && !b; out[3 * i + 1] = !a && b; out[3 * i + 2] = a && b;
+}
+
 // bootstrap key, standard domain, rows [i0, i0+ni) x rows_per_bit: GLWE(0) + s_i * gadget.
 // One block per row; the mask polynomial is parked in LDS while the body accumulates A * S.
 __global__ void k_bsk_gen_std(const uint8_t* __restrict__ s_small, const uint8_t* __restrict__ S_glwe, int i0, int k, int N, int l,
@@ -339,6 +347,7 @@ struct pbs_launch {
   int n, beta;
   const cplx* bsk;
   const cplx* tw;             // twiddle table in global memory
+  const cplx* wtab;           // two-bit kernels: e^{i pi m / N}, m < 2N
   const int64_t* tables;      // [ntab][2^w]
   int w;
   const int32_t* table_idx;   // optional explicit index per ciphertext
@@ -353,10 +362,10 @@ struct pbs_launch {
   int pf_parts;               // 0: no L2 warm-up; else each workgroup touches 1/pf_parts of the next key rows
 };
 
-template <int LOGN, int K, int L, int P, int GROUPS>
-__global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P>::T * GROUPS), ((P >= 16 || (pbs_geom<LOGN, K, L, P>::T * GROUPS) >= 512) ? 1 : 2))
+template <int LOGN, int K, int L, int P, int GROUPS, int MB = 0>
+__global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P, MB>::T * GROUPS), ((P >= 16 || (pbs_geom<LOGN, K, L, P, MB>::T * GROUPS) >= 512) ? 1 : 2))
 pbs_kernel(pbs_launch a) {
-  using G = pbs_geom<LOGN, K, L, P>;
+  using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int T = G::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   cplx* tw = reinterpret_cast<cplx*>(smem_raw);
@@ -388,14 +397,15 @@ pbs_kernel(pbs_launch a) {
   A.body_add = a.body_add;
   A.bsk_wrap = a.bsk_wrap;
   A.pf_parts = a.pf_parts;
+  A.wtab = a.wtab;
   if constexpr (G::TWIST_LDS) A.twist = tw + G::F::TW_TOTAL; else A.twist = a.tw + G::F::TW_TOTAL;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
   if constexpr (T <= 64) {
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
     // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
-    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
   } else {
-    pbs_thread<LOGN, K, L, P>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
   }
 }
 

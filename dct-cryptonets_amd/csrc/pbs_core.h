@@ -19,8 +19,10 @@ namespace dctfhe {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DCTFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define DCTFHE_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))   // the value is the same in every lane of the wave
 #else
 #define DCTFHE_SCHED_BARRIER() ((void)0)
+#define DCTFHE_UNIFORM(x) (x)
 #endif
 
 // key loads in flight per thread between two waits: 8 spilled more than it hid, 2 exposed the latency
@@ -42,7 +44,8 @@ namespace dctfhe {
 #define PBS_PF_DIST 2
 #endif
 
-template <int LOGN, int K, int L, int P>
+// MB = 1: two-bit blind rotation (see pbs_thread); needs the pair geometry (k = 1, one level).
+template <int LOGN, int K, int L, int P, int MB = 0>
 struct pbs_geom {
   static constexpr int N = 1 << LOGN;
   static constexpr int LOGM = LOGN - 1;
@@ -59,7 +62,14 @@ struct pbs_geom {
   // PAIR: the K+1 = 2 forward transforms of a one-level k = 1 bootstrap run interleaved (fft_forward_n), and so do
   // the two inverse ones: LDS scatter/gather of one polynomial overlaps the butterflies of the other, and the
   // barrier count per CMUX drops from 11 to 6.  Costs a second exchange buffer; the rotation stages alias the two.
-  static constexpr bool PAIR = PBS_PAIR && K == 1 && L == 1;
+  static constexpr bool PAIR = (PBS_PAIR || MB) && K == 1 && L == 1;
+  static_assert(!MB || PAIR, "the two-bit rotation is written for k = 1, one level");
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!MB || F::T >= 64, "two-bit kernels assume one ciphertext per wave");
+#endif
+  static constexpr int KEY_BLOCKS = MB ? 3 : 1;        // key-bit-sized blocks read per loop iteration
+  static constexpr int RL = F::radix(F::S - 1);        // radix of the last pass
+  static constexpr int NG = P / RL;                    // small transforms per thread in the last pass
   static constexpr int NL_AUTO = (K >= 2 || L >= 3) ? 1 : 0;
   static constexpr int NL = PBS_LDS_POLYS < 0 ? NL_AUTO : (PBS_LDS_POLYS < K ? PBS_LDS_POLYS : K);
   static constexpr int STAGE_BYTES = N * 8;
@@ -120,21 +130,30 @@ struct pbs_args {
   int accumulate;             // 0: out = extract(ACC) (mask beyond K*N zeroed); 1: out += extract(ACC)
   uint64_t body_add;          // added to the body word (accumulate mode: the "- v" of a bit step)
   int bsk_wrap;               // 0 = off; >0: key bit i reads BSK[i % bsk_wrap] (cache experiments only)
+  const cplx* wtab;           // MB: e^{i pi m / N}, m < 2N (monomials in the Fourier domain), then e^{2 pi i k / 8}, k < 8
   const cplx* twist;          // the T twist bases e^{i pi t/N} (entries TW_TOTAL.. of the twiddle table; LDS or global)
   int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
 };
 
 // The whole bootstrap for one ciphertext, executed by thread t of its group.
-template <int LOGN, int K, int L, int P, class Sync, class WSync>
+//
+// MB = 1, two key bits per iteration (Zhou et al. style unrolling, arranged so that the transforms are shared):
+//   X^{a1 s1 + a2 s2} = 1 + s1(1-s2) (X^{a1} - 1) + (1-s1)s2 (X^{a2} - 1) + s1 s2 (X^{a1+a2} - 1)
+//   ACC += sum_w (X^{e_w} - 1) * (GGSW(b_w) [x] ACC),   (b_w, e_w) as above.
+// The gadget decomposition is of ACC itself -- one decomposition, K+1 forward transforms and K+1 inverse transforms per
+// PAIR of key bits, no rotation through LDS -- and the monomials act in the Fourier domain, where X^e is the pointwise
+// factor zeta^e, zeta = e^{i pi (1-4k)/N} the evaluation point (spectrum_freq).  Price: three key blocks per pair
+// instead of two, and the key/FFT noise of three products scaled by |X^e - 1|^2 = 2 (dctfhe/params.py prices it).
+template <int LOGN, int K, int L, int P, int MB = 0, class Sync, class WSync>
 HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, uint64_t* accl, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
-  using G = pbs_geom<LOGN, K, L, P>;
+  using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
   const int n = A.n;
   const int msh = 64 - LOGN - 2;
   const cplx twist = A.twist[t];
 
   // L2 warm-up geometry: this workgroup owns lines [pf_line0, pf_line0 + pf_per) of every key bit
-  constexpr int PF_LINES = (int)(G::BSK_ELEMS_PER_KEYBIT * 16 / 128);
+  constexpr int PF_LINES = (int)(G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT * 16 / 128);
   constexpr int PF_ROUNDS = (PF_LINES / 8 + T - 1) / T;      // touches per thread per iteration; covers pf_parts >= 8
   const char* pf_ptr;
   {
@@ -143,7 +162,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
     int line = A.pf_rank * per + (t < per ? t : per - 1);
     if (line > PF_LINES - 1 - (PF_ROUNDS - 1) * T) line = PF_LINES - 1 - (PF_ROUNDS - 1) * T;
     if (line < 0) line = 0;
-    pf_ptr = reinterpret_cast<const char*>(A.bsk + (size_t)PBS_PF_DIST * G::BSK_ELEMS_PER_KEYBIT) + (size_t)line * 128;
+    pf_ptr = reinterpret_cast<const char*>(A.bsk + (size_t)PBS_PF_DIST * G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT) + (size_t)line * 128;
   }
   uint64_t acc[K + 1][2 * P];
   {  // ACC = X^{-b~} * TV (trivial GLWE)
@@ -164,11 +183,78 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
     });
   }
 
-  for (int i = 0; i < n; i++) {
+  // MB: root exponent (1 - 4k) mod 2N of this thread's first point in each small transform of the last pass; point j' of
+  // small transform g sits at exponent ulow[g] - j' * (2N / RL)
+  uint32_t ulow[G::NG];
+  if constexpr (MB) {
+    static_for<0, G::NG>([&](auto Gg) {
+      constexpr int g = decltype(Gg)::value;
+      ulow[g] = (uint32_t)(1 - 4 * spectrum_freq<G::LOGM, P>(P * t + g * G::RL)) & (2 * N - 1);
+    });
+  }
+
+  for (int i = 0; i < n; i += (MB ? 2 : 1)) {
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT;
     cplx out[K + 1][P];
-    if constexpr (G::PAIR) {
+    if constexpr (MB) {
+      const uint32_t a2 = (uint32_t)(((A.ct_small[i + 1] >> msh) + 1) >> 1) & (2 * N - 1);
+      const cplx* key = A.bsk + (size_t)(3 * (i >> 1)) * G::BSK_ELEMS_PER_KEYBIT;     // blocks: b1 = s1(1-s2), b2 = (1-s1)s2, b12 = s1 s2
+      cplx v[2][P];
+      static_for<0, 2>([&](auto Pp) {
+        constexpr int p = decltype(Pp)::value;
+        static_for<0, 2 * P>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          int32_t dg[1];
+          decompose<1>(acc[p][r], A.beta, dg);
+          if constexpr (r < P) v[p][r].re = (double)dg[0]; else v[p][r - P].im = (double)dg[0];
+        });
+      });
+      fft_forward_n<G::LOGM, P, 2>(v, t, tw, twist, exch, sync, wsync);
+      // zeta^{a} at this thread's points: one 16-byte gather per exponent and small transform from the 2N-entry root
+      // table; inside a small transform the points are RL-th roots of unity apart, zeta_{j'} = zeta_0 * e^{-2 pi i a j'/RL}
+      // -- a factor that only depends on a (the same for the whole ciphertext), read from the 8-entry table below.
+      // (a wave holds threads of one ciphertext only: T >= 64 on the device)
+      const uint32_t au = DCTFHE_UNIFORM(a), a2u = DCTFHE_UNIFORM(a2);
+      cplx zb1 = cmk(1.0, 0.0), zb2 = cmk(1.0, 0.0);
+      static_for<0, P>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int g = j / G::RL, jp = j % G::RL;
+        if constexpr (jp == 0) {
+          zb1 = A.wtab[(a * ulow[g]) & (2 * N - 1)];
+          zb2 = A.wtab[(a2 * ulow[g]) & (2 * N - 1)];
+        }
+        cplx z1 = zb1, z2 = zb2;
+        if constexpr (jp > 0) {
+          z1 = cmul(z1, A.wtab[2 * N + (((0u - au * (uint32_t)jp) * (8 / G::RL)) & 7)]);     // wave-uniform address: one line per load
+          z2 = cmul(z2, A.wtab[2 * N + (((0u - a2u * (uint32_t)jp) * (8 / G::RL)) & 7)]);
+        }
+        static_for<0, 2>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          cplx kk[3][2];
+          static_for<0, 3>([&](auto Ww) {
+            constexpr int w = decltype(Ww)::value;
+            static_for<0, 2>([&](auto Rr) {
+              constexpr int r = decltype(Rr)::value;
+#if defined(DCTFHE_ABLATE_BSK)
+              kk[w][r] = cmk(1.0 + w, 0.5 * q + r);
+#else
+              kk[w][r] = key[(size_t)((w * 2 + r) * 2 + q) * M + j * T + t];
+#endif
+            });
+          });
+          DCTFHE_SCHED_BARRIER();
+          const cplx m1 = cmk(z1.re - 1.0, z1.im), m2 = cmk(z2.re - 1.0, z2.im);
+          cplx m12 = cmul(z1, z2); m12.re -= 1.0;
+          static_for<0, 2>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            const cplx bundle = cfma(m12, kk[2][r], cfma(m2, kk[1][r], cmul(m1, kk[0][r])));
+            if constexpr (r == 0) out[q][j] = cmul(v[0][j], bundle); else out[q][j] = cfma(v[1][j], bundle, out[q][j]);
+          });
+          DCTFHE_SCHED_BARRIER();
+        });
+      });
+    } else if constexpr (G::PAIR) {
       // both accumulator polynomials go through their stages at once (stage p = exchange buffer p; everybody is past
       // the last gather of the previous inverse transforms: their trailing barrier), one barrier, then the rotated
       // reads; the leading barrier of the forward transforms covers those reads.
@@ -302,7 +388,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
 #else
       pf_dump[t] = acc_pf;
 #endif
-      pf_ptr += G::BSK_ELEMS_PER_KEYBIT * 16;
+      pf_ptr += G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT * 16;
     }
 
     if constexpr (G::PAIR) fft_inverse_n<G::LOGM, P, 2>(out, t, tw, twist, exch, sync, wsync);

@@ -17,6 +17,7 @@ MAX_TIERS = 8
 class Tier(C.Structure):
     _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("logN", C.c_int32), ("l", C.c_int32), ("beta", C.c_int32),
                 ("lk", C.c_int32), ("betak", C.c_int32), ("ksk_share", C.c_int32),
+                ("unroll", C.c_int32), ("reserved", C.c_int32),
                 ("lwe_sigma", C.c_double), ("glwe_sigma", C.c_double)]
 
 

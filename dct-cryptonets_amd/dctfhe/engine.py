@@ -8,12 +8,12 @@ from ._lib import Params, Stats, Tier, Timing, check, ptr
 
 
 def make_params(D, n_max, tiers, input_sigma):
-    """tiers: list of dicts with n,k,logN,l,beta,lk,betak,lwe_sigma,glwe_sigma[,ksk_share]."""
+    """tiers: list of dicts with n,k,logN,l,beta,lk,betak,lwe_sigma,glwe_sigma[,ksk_share][,unroll]."""
     p = Params()
     p.D, p.n_max, p.n_tiers, p.input_sigma = D, n_max, len(tiers), input_sigma
     for i, t in enumerate(tiers):
         p.tiers[i] = Tier(t["n"], t["k"], t["logN"], t["l"], t["beta"], t["lk"], t["betak"], t.get("ksk_share", -1),
-                          t["lwe_sigma"], t["glwe_sigma"])
+                          t.get("unroll", 1), 0, t["lwe_sigma"], t["glwe_sigma"])
     return p
 
 
@@ -76,7 +76,8 @@ class Keys:
 
     def export_bsk(self, tier):
         t = self.tier(tier)
-        out = np.empty((t.n, (t.k + 1) * t.l, t.k + 1, 1 << t.logN), np.uint64)
+        blocks = 3 * t.n // 2 if t.unroll == 2 else t.n        # unroll 2: the key of the pair secret
+        out = np.empty((blocks, (t.k + 1) * t.l, t.k + 1, 1 << t.logN), np.uint64)
         check(self.L.dctfhe_keys_export_bsk(self.h, tier, ptr(out)))
         return out
 

@@ -29,6 +29,7 @@ class TierSpec:
     lk: int
     betak: int
     ksk_share: int = -1
+    unroll: int = 1            # key bits per blind-rotate iteration (2: two-bit rotation, csrc/pbs_core.h; k = 1, l = 1 only)
     lwe_sigma: float = 0.0
     glwe_sigma: float = 0.0
 
@@ -94,6 +95,13 @@ def var_pbs_out(t, fft_c=2.0):
     # f64 FFT rounding of the external product, measured on the GPU (tools/noise_probe.py) and on the CPU oracle
     # against the exact schoolbook product (tests/emul): per CMUX  c * (k+1) l N^2 B^2/12 * 2^-106, c ~ 2.
     fft = fft_c * (t.k + 1) * t.l * float(t.N) ** 2 * (B * B / 12.0) * 2.0 ** -106
+    if getattr(t, "unroll", 1) == 2:
+        # two-bit rotation, per PAIR: three products scaled by (X^e - 1) (variance x2) -> key and FFT noise 6 units instead
+        # of 2; the single decomposition error enters through (X^e - 1) b_w, one of the three b_w set with probability
+        # 3/4 -> 1.5 units where the one-bit chain has 2 x 1/2 (the formula above counts a unit per CMUX, twice the truth)
+        key = t.l * (t.k + 1) * t.N * ((B * B + 2) / 12.0) * t.glwe_sigma ** 2
+        dec = (kN / 2.0 + 1.0) * 2.0 ** (-2 * t.beta * t.l) / 12.0
+        return (t.n / 2.0) * (6.0 * key + 3.0 * dec + 6.0 * fft)
     return t.n * (ext + fft)
 
 
@@ -116,11 +124,11 @@ def default_params():
     output is subtracted from a p-bit accumulator."""
     t6 = TierSpec("T6", n=864, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
     t5 = TierSpec("T5", n=864, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
-    t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0)
+    t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0, unroll=2)
     b = TierSpec("B", n=660, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
-    t6a = TierSpec("T6a", n=864, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0)
+    t6a = TierSpec("T6a", n=864, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     # Ba: one-level bit tier.  The output of rounding step i is amplified by 2^(p-j) only in the later steps j > i,
     # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
     # site, the first step from which Ba is safe.
@@ -129,7 +137,7 @@ def default_params():
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
     t4r = TierSpec("T4r", n=864, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
     # T5a: one-level twin of T5; the 5-bit residual-sum table is split the same way (T5a + T4r ~0.9x of T5)
-    t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0)
+    t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
                     coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5)
 

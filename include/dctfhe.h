@@ -42,6 +42,8 @@ typedef struct {
   int32_t l, beta;      /* bootstrap gadget: levels, base log */
   int32_t lk, betak;    /* key-switch gadget: levels, base log */
   int32_t ksk_share;    /* >= 0: reuse the key-switch key of that (earlier) tier; -1: own key */
+  int32_t unroll;       /* key bits per blind-rotate iteration: 1, or 2 (k = 1, l = 1, n even; key of 3n/2 blocks) */
+  int32_t reserved;
   double lwe_sigma;     /* noise std of key-switch-key rows (fraction of the torus) */
   double glwe_sigma;    /* noise std of bootstrap-key rows */
 } dctfhe_tier;

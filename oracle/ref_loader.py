@@ -60,6 +60,10 @@ def lib():
     L.ref_round_lut_batch.argtypes = [u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(RefTier),
                                       C.POINTER(RefTier), i64p, C.c_int, C.c_void_p, u64p]
     L.ref_round_lut_batch.restype = C.c_int
+    L.ref_pair_secret.argtypes = [u8p, C.c_int, u8p]
+    L.ref_pbs_mb2_batch.argtypes = [u64p, C.c_int, C.c_int, u64p, C.c_int, C.c_int, C.c_int, C.c_int, i64p, C.c_int, C.c_void_p,
+                                    C.c_int, u64p]
+    L.ref_pbs_mb2_batch.restype = C.c_int
     L.ref_num_threads.restype = C.c_int
     L.ref_set_num_threads.argtypes = [C.c_int]
     _LIB = L
@@ -126,6 +130,25 @@ def pbs(cts_small, bsk_f, bsk, k, N, l, beta, tables, w, table_idx, D_out, exact
                         None if bsk_f is None else bsk_f.ctypes.data, None if bsk is None else bsk.ctypes.data,
                         1 if exact else 0, k, N, l, beta, tables, w,
                         None if idx is None else idx.ctypes.data, D_out, out)
+    return out
+
+
+def pair_secret(s):
+    out = np.zeros(3 * (s.size // 2), np.uint8)
+    lib().ref_pair_secret(np.ascontiguousarray(s, np.uint8), s.size, out)
+    return out
+
+
+def pbs_mb2(cts_small, bsk3, k, N, l, beta, tables, w, table_idx, D_out):
+    """two-bit blind rotation in exact arithmetic; bsk3 = standard-domain key of pair_secret(s) (3n/2 blocks)"""
+    cts_small = np.ascontiguousarray(cts_small, np.uint64)
+    count, n1 = cts_small.shape
+    tables = np.ascontiguousarray(tables, np.int64).reshape(-1, 1 << w)
+    idx = None if table_idx is None else np.ascontiguousarray(table_idx, np.int32)
+    out = np.zeros((count, D_out + 1), np.uint64)
+    rc = lib().ref_pbs_mb2_batch(cts_small, count, n1 - 1, np.ascontiguousarray(bsk3, np.uint64), k, N, l, beta, tables, w,
+                                 None if idx is None else idx.ctypes.data, D_out, out)
+    assert rc == 0
     return out
 
 

@@ -456,6 +456,69 @@ int ref_pbs_batch(const uint64_t *cts_small, int count, int n,
   return 0;
 }
 
+/* ------------------------------------------------------------------ two-bit blind rotation (product: pbs_core.h, MB = 1)
+ * [K: Zhou, Yang, Zhang, Wang, "Faster bootstrapping with multiple addends", 2018; Bourse et al.]
+ *   X^{a1 s1 + a2 s2} = 1 + s1(1-s2)(X^{a1}-1) + (1-s1)s2 (X^{a2}-1) + s1 s2 (X^{a1+a2}-1)
+ *   ACC += sum_w (X^{e_w} - 1) * (GGSW(b_w) [x] ACC)
+ * The key is an ordinary bootstrapping key for the derived secret of 3n/2 bits that ref_pair_secret builds.
+ * Exact arithmetic (schoolbook mod 2^64) only: this is the definition the device path is checked against. */
+void ref_pair_secret(const uint8_t *s, int n, uint8_t *out /* 3n/2 */) {
+  for (int i = 0; i + 1 < n; i += 2) {
+    out[3 * (i / 2) + 0] = (uint8_t)(s[i] && !s[i + 1]);
+    out[3 * (i / 2) + 1] = (uint8_t)(!s[i] && s[i + 1]);
+    out[3 * (i / 2) + 2] = (uint8_t)(s[i] && s[i + 1]);
+  }
+}
+
+int ref_pbs_mb2_batch(const uint64_t *cts_small, int count, int n, const uint64_t *bsk3 /* [3n/2][rows][k+1][N] */,
+                      int k, int N, int l, int beta, const int64_t *tables, int w, const int32_t *table_idx,
+                      int D_out, uint64_t *cts_out) {
+  if (n % 2) return -1;
+  const int rows = (k + 1) * l;
+  const size_t blk = (size_t)rows * (k + 1) * N;
+#pragma omp parallel
+  {
+    pbs_ws_t ws;
+    ws_alloc(&ws, n, k, N, l);
+    uint64_t *sum = (uint64_t *)malloc(sizeof(uint64_t) * (k + 1) * N);
+    uint64_t *keep = (uint64_t *)malloc(sizeof(uint64_t) * (k + 1) * N);
+#pragma omp for schedule(dynamic, 1)
+    for (int c = 0; c < count; c++) {
+      const uint64_t *ct = cts_small + (size_t)c * (n + 1);
+      uint64_t *out = cts_out + (size_t)c * (D_out + 1);
+      ref_modswitch(ct, n, N, ws.ms);
+      ref_build_testvector(tables + ((size_t)(table_idx ? table_idx[c] : 0) << w), w, N, ws.tv);
+      memset(ws.acc, 0, sizeof(uint64_t) * (size_t)k * N);
+      nega_rotate(ws.acc + (size_t)k * N, ws.tv, (2 * N - (int)ws.ms[n]) % (2 * N), N);
+      for (int i = 0; i < n; i += 2) {
+        const int e[3] = {(int)ws.ms[i], (int)ws.ms[i + 1], (int)((ws.ms[i] + ws.ms[i + 1]) % (2u * N))};
+        memcpy(ws.diff, ws.acc, sizeof(uint64_t) * (k + 1) * N);   /* the gadget decomposition is of ACC itself */
+        memcpy(keep, ws.acc, sizeof(uint64_t) * (k + 1) * N);
+        memset(sum, 0, sizeof(uint64_t) * (k + 1) * N);
+        for (int v = 0; v < 3; v++) {
+          memset(ws.acc, 0, sizeof(uint64_t) * (k + 1) * N);
+          external_product_exact(&ws, bsk3 + (size_t)(3 * (i / 2) + v) * blk, k, N, l, beta);   /* acc = GGSW(b_v) [x] ACC */
+          for (int p = 0; p <= k; p++) {
+            nega_rotate(ws.rot + (size_t)p * N, ws.acc + (size_t)p * N, e[v], N);
+            for (int x = 0; x < N; x++) sum[(size_t)p * N + x] += ws.rot[(size_t)p * N + x] - ws.acc[(size_t)p * N + x];
+          }
+        }
+        for (int x = 0; x < (k + 1) * N; x++) ws.acc[x] = keep[x] + sum[x];
+      }
+      for (int j = 0; j < k; j++) {
+        const uint64_t *A = ws.acc + (size_t)j * N;
+        out[(size_t)j * N] = A[0];
+        for (int m = 1; m < N; m++) out[(size_t)j * N + m] = (uint64_t)0 - A[N - m];
+      }
+      for (int j = k * N; j < D_out; j++) out[j] = 0;
+      out[D_out] = ws.acc[(size_t)k * N];
+    }
+    free(sum); free(keep);
+    ws_free(&ws);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ levelled ops */
 void ref_conv2d(const uint64_t *in, int Cin, int H, int W, int D, const int32_t *weight, int Cout,
                 int KH, int KW, int stride, int pad, uint64_t *out) {

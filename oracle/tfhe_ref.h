@@ -78,6 +78,13 @@ int ref_pbs_batch(const uint64_t *cts_small, int count, int n,
                   const int64_t *tables, int w, const int32_t *table_idx,
                   int D_out, uint64_t *cts_out);
 
+/* two-bit blind rotation (the product's one-level k = 1 tiers): definition in exact arithmetic.
+ * ref_pair_secret derives (s1(1-s2), (1-s1)s2, s1 s2) per pair; bsk3 = ref_bsk_gen of that 3n/2-bit secret. */
+void ref_pair_secret(const uint8_t *s, int n, uint8_t *out /* 3n/2 */);
+int ref_pbs_mb2_batch(const uint64_t *cts_small, int count, int n, const uint64_t *bsk3,
+                      int k, int N, int l, int beta, const int64_t *tables, int w, const int32_t *table_idx,
+                      int D_out, uint64_t *cts_out);
+
 /* levelled operators on ciphertext tensors (D+1 words per element, NCHW, batch folded by caller) */
 void ref_conv2d(const uint64_t *in, int Cin, int H, int W, int D,
                 const int32_t *weight /* [Cout][Cin][KH][KW] */, int Cout, int KH, int KW,

@@ -15,34 +15,42 @@
 
 using namespace dctfhe;
 
-template <int LOGN, int K, int L, int P>
-static int run_case(int n, int beta, int w, double sigma_bsk) {
-  using G = pbs_geom<LOGN, K, L, P>;
+// MB = 1: the two-bit blind rotation, checked against its exact-arithmetic definition (ref_pbs_mb2_batch)
+template <int LOGN, int K, int L, int P, int MB = 0>
+static int run_case(int n_in, int beta, int w, double sigma_bsk) {
+  using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int N = G::N, M = G::M, T = G::T;
   const int D = K * N, count = 6;
-  std::vector<uint8_t> S(D), s(n);
+  std::vector<uint8_t> S(D), s(n_in);
   ref_gen_binary_key(11, D, S.data());
-  ref_gen_binary_key(12, n, s.data());
+  ref_gen_binary_key(12, n_in, s.data());
   const int rows = (K + 1) * L;
+  const int n = MB ? 3 * n_in / 2 : n_in;          // key blocks
+  std::vector<uint8_t> skey(n);
+  if (MB) ref_pair_secret(s.data(), n_in, skey.data()); else skey = s;
   std::vector<uint64_t> bsk((size_t)n * rows * (K + 1) * N);
-  ref_bsk_gen(s.data(), n, S.data(), K, N, L, beta, sigma_bsk, 13, bsk.data());
+  ref_bsk_gen(skey.data(), n, S.data(), K, N, L, beta, sigma_bsk, 13, bsk.data());
   std::vector<double> bskf(bsk.size());
-  ref_bsk_to_fourier(bsk.data(), n, K, N, L, bskf.data());
+  if (!MB) ref_bsk_to_fourier(bsk.data(), n, K, N, L, bskf.data());
 
   // inputs: small-LWE encryptions of messages on w bits (+padding)
-  std::vector<uint64_t> phases(count), cts((size_t)count * (n + 1));
+  std::vector<uint64_t> phases(count), cts((size_t)count * (n_in + 1));
   for (int c = 0; c < count; c++) phases[c] = (uint64_t)((c * 5 + 1) % (1 << w)) << (63 - w);
-  ref_lwe_encrypt_batch(s.data(), n, n, phases.data(), count, 1e-9, 14, cts.data());
+  ref_lwe_encrypt_batch(s.data(), n_in, n_in, phases.data(), count, 1e-9, 14, cts.data());
   std::vector<int64_t> table(1 << w);
   for (int x = 0; x < (1 << w); x++) table[x] = (int64_t)(((x * 3 + 2) % (1 << w))) << (63 - w - 1);
 
   std::vector<uint64_t> ref_out((size_t)count * (D + 1));
-  ref_pbs_batch(cts.data(), count, n, bskf.data(), bsk.data(), 0, K, N, L, beta, table.data(), w, nullptr, D, ref_out.data());
+  if (MB) ref_pbs_mb2_batch(cts.data(), count, n_in, bsk.data(), K, N, L, beta, table.data(), w, nullptr, D, ref_out.data());
+  else ref_pbs_batch(cts.data(), count, n, bskf.data(), bsk.data(), 0, K, N, L, beta, table.data(), w, nullptr, D, ref_out.data());
 
   // ---- emulated device path
   std::vector<cplx> tw(G::F::TW_ELEMS);
   fill_twiddles<G::LOGM, P>(tw.data());
-  std::vector<cplx> bsk_dev((size_t)(n + PBS_PF_DIST) * G::BSK_ELEMS_PER_KEYBIT);
+  std::vector<cplx> bsk_dev((size_t)(n + PBS_PF_DIST * G::KEY_BLOCKS) * G::BSK_ELEMS_PER_KEYBIT);
+  std::vector<cplx> wtab(2 * N + 8);
+  for (int m = 0; m < 2 * N; m++) { const long double a = 3.141592653589793238462643383279502884L * m / N; wtab[m] = cmk((double)cosl(a), (double)sinl(a)); }
+  for (int m = 0; m < 8; m++) wtab[2 * N + m] = root64(8 * m);
   std::vector<unsigned char> shared(G::SHARED_BYTES);   // rotation stage aliases the exchange buffer, as on the device
   std::vector<uint64_t> accl((size_t)G::NL * N + 1);
   std::vector<uint32_t> pfd(T);
@@ -57,10 +65,10 @@ static int run_case(int n, int beta, int w, double sigma_bsk) {
       sync();   // on the device the key conversion is a separate kernel: nobody is still gathering when the bootstrap starts
       for (int c = 0; c < count; c++) {
         pbs_args A;
-        A.ct_small = cts.data() + (size_t)c * (n + 1); A.n = n; A.beta = beta; A.bsk = bsk_dev.data();
+        A.ct_small = cts.data() + (size_t)c * (n_in + 1); A.n = n_in; A.wtab = wtab.data(); A.beta = beta; A.bsk = bsk_dev.data();
         A.table = table.data(); A.w = w; A.out = emu_out.data() + (size_t)c * (D + 1); A.D_out = D;
         A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = 0;
-        pbs_thread<LOGN, K, L, P>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
+        pbs_thread<LOGN, K, L, P, MB>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
         sync();
       }
     };
@@ -83,7 +91,7 @@ static int run_case(int n, int beta, int w, double sigma_bsk) {
     const int got = (int)(((ph_emu[c] + (1ULL << (63 - w - 2))) >> (63 - w - 1)) & ((1 << (w + 1)) - 1));
     if (got != (int)(want >> (63 - w - 1))) bad++;
   }
-  std::printf("N=%d k=%d l=%d P=%d T=%d n=%d: wrong=%d max|emu-ref|=%.3g max|emu-ideal|=%.3g\n", N, K, L, P, T, n, bad, maxd, maxe);
+  std::printf("%sN=%d k=%d l=%d P=%d T=%d n=%d: wrong=%d max|emu-ref|=%.3g max|emu-ideal|=%.3g\n", MB ? "two-bit " : "", N, K, L, P, T, n_in, bad, maxd, maxe);
   // a rounding flip in one decomposition gives a different but equivalent ciphertext, so the two
   // implementations agree only up to the scheme's own noise: bound both against the ideal value
   return bad || maxe > std::ldexp(1.0, -(w + 4));
@@ -150,6 +158,9 @@ int main() {
   fail |= run_case<10, 1, 2, 16>(12, 12, 4, 1e-13);
   fail |= run_case<9, 1, 1, 8>(16, 20, 3, 1e-13);    // one level, k = 1: the pair-interleaved path
   fail |= run_case<11, 1, 1, 8>(8, 22, 4, 1e-14);
+  fail |= run_case<9, 1, 1, 8, 1>(16, 20, 3, 1e-13);   // two-bit blind rotation, last pass radix 4
+  fail |= run_case<10, 1, 1, 8, 1>(12, 20, 3, 1e-13);  // ... radix 8
+  fail |= run_case<11, 1, 1, 8, 1>(8, 22, 4, 1e-14);   // ... radix 2
   std::printf(fail ? "EMUL FAIL\n" : "EMUL OK\n");
   return fail;
 }

@@ -86,6 +86,38 @@ def test_pbs_all_messages(keys, oracle, tier, w):
     assert not dev[:, t["k"] * N: D_SMALL].any()
 
 
+def test_pbs_two_bit_rotation(gpu_ctx, oracle):
+    """tier.unroll == 2 (two key bits per blind-rotate iteration, csrc/pbs_core.h): every message decodes to f(m), the
+    exported key is a bootstrapping key of the pair secret, and the device agrees with the exact-arithmetic definition
+    (oracle ref_pbs_mb2_batch) on decrypted values and on the size of the noise."""
+    from dctfhe.engine import Keys, make_params
+    D, w = 2048, 3
+    tier = dict(n=40, k=1, logN=11, l=1, beta=20, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52, unroll=2)
+    k = Keys(gpu_ctx, make_params(D, 40, [tier], 2.0 ** -50), seed=21)
+    try:
+        S, s = k.export_secret()
+        msgs = np.arange(1 << w, dtype=np.uint64)
+        small = oracle.lwe_encrypt(s[:40].copy(), 40, msgs << np.uint64(63 - w), 2.0 ** -30, seed=13)
+        f = (msgs * 3 + 1) % (1 << w)
+        table = f.astype(np.int64) << (63 - w - 2)
+        dev = k.pbs(0, small, table, w)
+        bsk3 = k.export_bsk(0)
+        assert bsk3.shape[0] == 60                                   # 3n/2 key blocks
+        # block 3i+v of the key encrypts bit v of the pair secret: phase of the body row's gadget coefficient
+        ps = oracle.pair_secret(s[:40].copy())
+        assert ps.reshape(-1, 3).sum(axis=1).max() <= 1 and ps.sum() > 0
+        ref = oracle.pbs_mb2(small, bsk3, 1, 2048, 1, 20, table, w, None, D)
+        ph_dev, ph_ref = oracle.lwe_phase(S, D, dev), oracle.lwe_phase(S, D, ref)
+        want = table.astype(np.uint64)
+        dec = lambda ph: ((ph + (np.uint64(1) << np.uint64(63 - w - 3))) >> np.uint64(63 - w - 2)) & np.uint64((1 << (w + 2)) - 1)
+        assert np.array_equal(dec(ph_dev), f.astype(np.uint64))
+        assert np.array_equal(dec(ph_ref), f.astype(np.uint64))
+        err_dev, err_ref = np.abs(_centered(ph_dev - want)), np.abs(_centered(ph_ref - want))
+        assert err_dev.max() < max(4 * err_ref.max(), 2.0 ** -30), (err_dev.max(), err_ref.max())
+    finally:
+        k.close()
+
+
 def test_pbs_negacyclic_rule(keys, oracle):
     """LUT[m + 2^w] = -LUT[m]: a message with the padding bit set comes back negated."""
     S, s = keys.export_secret()
