@@ -44,7 +44,7 @@ namespace dctfhe {
 #define PBS_PF_DIST 2
 #endif
 
-// MB = 1: two-bit blind rotation (see pbs_thread); needs the pair geometry (k = 1, one level).
+// MB = 1: two-bit blind rotation (see pbs_thread).
 template <int LOGN, int K, int L, int P, int MB = 0>
 struct pbs_geom {
   static constexpr int N = 1 << LOGN;
@@ -63,7 +63,6 @@ struct pbs_geom {
   // the two inverse ones: LDS scatter/gather of one polynomial overlaps the butterflies of the other, and the
   // barrier count per CMUX drops from 11 to 6.  Costs a second exchange buffer; the rotation stages alias the two.
   static constexpr bool PAIR = (PBS_PAIR || MB) && K == 1 && L == 1;
-  static_assert(!MB || PAIR, "the two-bit rotation is written for k = 1, one level");
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!MB || F::T >= 64, "two-bit kernels assume one ciphertext per wave");
 #endif
@@ -79,7 +78,7 @@ struct pbs_geom {
   static constexpr bool ALIAS = NL > 0 || PAIR;
   static_assert(!PAIR || (NL == 0 && EXCH_BYTES >= STAGE_BYTES), "pair mode stages each polynomial in its exchange buffer");
   static constexpr int STAGE_OFFSET = ALIAS ? 0 : EXCH_BYTES;
-  static constexpr int SHARED_BYTES = PAIR ? 2 * EXCH_BYTES : ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
+  static constexpr int SHARED_BYTES = PAIR ? 2 * EXCH_BYTES : MB ? EXCH_BYTES /* no rotation stage */ : ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
   static constexpr int ACCL_BYTES = NL * N * 8;
   static constexpr int GROUP_BYTES = SHARED_BYTES + ACCL_BYTES;
   // twiddle table in LDS, shared by all groups of a workgroup; the pair kernels of the two big rings are short of
@@ -117,6 +116,15 @@ HD uint64_t testvec_coeff(const int64_t* table, int w, int N, int j) {
   const int jj = j + half;
   return (jj < N) ? (uint64_t)table[jj / box] : (uint64_t)0 - (uint64_t)table[0];
 }
+
+// e^{2 pi i k / 8} for a wave-uniform k: constant address space, so the device reads it with scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ const double dctfhe_cos8[8] = {1.0, 0.70710678118654752440, 0.0, -0.70710678118654752440,
+                                                       -1.0, -0.70710678118654752440, 0.0, 0.70710678118654752440};
+HD cplx root8(uint32_t k) { return cmk(dctfhe_cos8[k & 7], dctfhe_cos8[(k + 6) & 7]); }
+#else
+HD cplx root8(uint32_t k) { return root64(8 * (int)(k & 7)); }
+#endif
 
 struct pbs_args {
   const uint64_t* ct_small;   // this ciphertext: n+1 words
@@ -197,7 +205,78 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT;
     cplx out[K + 1][P];
-    if constexpr (MB) {
+    if constexpr (MB && !G::PAIR) {
+      // general (k, l): one polynomial at a time through the single exchange buffer; the monomial factors are rebuilt per
+      // gadget row (holding them for all P points would take 96 registers).  ACC polynomials that live in LDS are only
+      // ever touched by their owner here -- there is no rotation -- so no barrier guards them.
+      const uint32_t a2 = (uint32_t)(((A.ct_small[i + 1] >> msh) + 1) >> 1) & (2 * N - 1);
+      const uint32_t au = DCTFHE_UNIFORM(a), a2u = DCTFHE_UNIFORM(a2);
+      const cplx* key = A.bsk + (size_t)(3 * (i >> 1)) * G::BSK_ELEMS_PER_KEYBIT;
+      static_for<0, K + 1>([&](auto Pp) {
+        constexpr int p = decltype(Pp)::value;
+        static_assert(L <= 3, "packing holds two deferred digits");
+        uint32_t packed[2 * P];
+        double first[2 * P];
+        static_for<0, 2 * P>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          uint64_t own;
+          if constexpr (p < NL) own = accl[p * N + t + T * r]; else own = acc[p][r];
+          int32_t dg[L];
+          decompose<L>(own, A.beta, dg);
+          first[r] = (double)dg[0];
+          uint32_t pk = 0;
+          if constexpr (L > 1) pk = (uint32_t)(uint16_t)(int16_t)dg[1];
+          if constexpr (L > 2) pk |= (uint32_t)(uint16_t)(int16_t)dg[2] << 16;
+          packed[r] = pk;
+        });
+        static_for<0, L>([&](auto Lv) {
+          constexpr int lev = decltype(Lv)::value;
+          constexpr int row = p * L + lev;
+          cplx v[P];
+          static_for<0, P>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (lev == 0) v[j] = cmk(first[j], first[P + j]);
+            else v[j] = cmk((double)(int16_t)(packed[j] >> (16 * (lev - 1))), (double)(int16_t)(packed[P + j] >> (16 * (lev - 1))));
+          });
+          fft_forward<G::LOGM, P>(v, t, tw, twist, exch, sync, wsync);
+          cplx zb1 = cmk(1.0, 0.0), zb2 = cmk(1.0, 0.0);
+          static_for<0, P>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int g = j / G::RL, jp = j % G::RL;
+            if constexpr (jp == 0) {
+              zb1 = A.wtab[(a * ulow[g]) & (2 * N - 1)];
+              zb2 = A.wtab[(a2 * ulow[g]) & (2 * N - 1)];
+            }
+            cplx z1 = zb1, z2 = zb2;
+            if constexpr (jp > 0) {
+              z1 = cmul(z1, root8((0u - au * (uint32_t)jp) * (8 / G::RL)));
+              z2 = cmul(z2, root8((0u - a2u * (uint32_t)jp) * (8 / G::RL)));
+            }
+            cplx kk[3][K + 1];
+            static_for<0, 3>([&](auto Ww) {
+              constexpr int w = decltype(Ww)::value;
+              static_for<0, K + 1>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+#if defined(DCTFHE_ABLATE_BSK)
+                kk[w][q] = cmk(1.0 + w, 0.5 * q + row);
+#else
+                kk[w][q] = key[((size_t)w * G::ROWS * (K + 1) + (size_t)row * (K + 1) + q) * M + j * T + t];
+#endif
+              });
+            });
+            DCTFHE_SCHED_BARRIER();
+            const cplx m1 = cmk(z1.re - 1.0, z1.im), m2 = cmk(z2.re - 1.0, z2.im);
+            cplx m12 = cmul(z1, z2); m12.re -= 1.0;
+            static_for<0, K + 1>([&](auto Q) {
+              constexpr int q = decltype(Q)::value;
+              const cplx bundle = cfma(m12, kk[2][q], cfma(m2, kk[1][q], cmul(m1, kk[0][q])));
+              if constexpr (row == 0) out[q][j] = cmul(v[j], bundle); else out[q][j] = cfma(v[j], bundle, out[q][j]);
+            });
+            DCTFHE_SCHED_BARRIER();
+          });
+        });
+      });
+    } else if constexpr (MB) {
       const uint32_t a2 = (uint32_t)(((A.ct_small[i + 1] >> msh) + 1) >> 1) & (2 * N - 1);
       const cplx* key = A.bsk + (size_t)(3 * (i >> 1)) * G::BSK_ELEMS_PER_KEYBIT;     // blocks: b1 = s1(1-s2), b2 = (1-s1)s2, b12 = s1 s2
       cplx v[2][P];
@@ -226,8 +305,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         }
         cplx z1 = zb1, z2 = zb2;
         if constexpr (jp > 0) {
-          z1 = cmul(z1, A.wtab[2 * N + (((0u - au * (uint32_t)jp) * (8 / G::RL)) & 7)]);     // wave-uniform address: one line per load
-          z2 = cmul(z2, A.wtab[2 * N + (((0u - a2u * (uint32_t)jp) * (8 / G::RL)) & 7)]);
+          z1 = cmul(z1, root8((0u - au * (uint32_t)jp) * (8 / G::RL)));      // wave-uniform: scalar loads
+          z2 = cmul(z2, root8((0u - a2u * (uint32_t)jp) * (8 / G::RL)));
         }
         static_for<0, 2>([&](auto Q) {
           constexpr int q = decltype(Q)::value;

@@ -161,6 +161,9 @@ int main() {
   fail |= run_case<9, 1, 1, 8, 1>(16, 20, 3, 1e-13);   // two-bit blind rotation, last pass radix 4
   fail |= run_case<10, 1, 1, 8, 1>(12, 20, 3, 1e-13);  // ... radix 8
   fail |= run_case<11, 1, 1, 8, 1>(8, 22, 4, 1e-14);   // ... radix 2
+  fail |= run_case<9, 2, 1, 8, 1>(16, 16, 3, 1e-13);   // two-bit, general path: k = 2
+  fail |= run_case<9, 1, 3, 8, 1>(16, 7, 4, 1e-12);    // ... three levels, first accumulator polynomial in LDS
+  fail |= run_case<10, 1, 2, 16, 1>(12, 12, 4, 1e-13); // ... 16 points per thread
   std::printf(fail ? "EMUL FAIL\n" : "EMUL OK\n");
   return fail;
 }
