@@ -156,7 +156,8 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
 #define X(LN)                                                                                        \
   if (t.logN == LN && t.k == 1 && t.l == 1 && t.unroll == 2) {                                       \
     using G = pbs_geom<LN, 1, 1, 8, 1>;                                                              \
-    constexpr int GR = groups_for<LN, 1, 1, 8>();                                                    \
+    /* N = 4096: two ciphertexts per 512-thread workgroup share their key lines (28.5 vs 30.8 ms) */  \
+    constexpr int GR = LN == 12 ? 2 : groups_for<LN, 1, 1, 8>();                                     \
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                    \
     static bool attr_done = false;                                                                   \
     if (!attr_done) {                                                                                \

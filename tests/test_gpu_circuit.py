@@ -65,5 +65,11 @@ def test_cli_mirror_simulate_mode():
            "--p_error", "0.01"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(os.environ.get("TMPDIR", "/tmp")))
     assert out.returncode == 0, out.stderr[-2000:]
-    for needle in ("Time for FHE compilation", "Max bit-width:", "it works in FHE!!", "Keygen time:", "Time per inference in FHE"):
+    for needle in ("Time for FHE compilation", "Max bit-width:", "it works in FHE!!", "Keygen time:", "Time per inference in FHE",
+                   "Encrypted Reliability Analysis Results", "Encrypted top1 acc:", "Done"):
         assert needle in out.stdout, out.stdout
+    # the sweep of the reference (random states 27, 28): encrypted == unencrypted on every subset at the exact tiers
+    import re
+    plain = re.search(r"Unencrypted top1 acc: (.*)", out.stdout).group(1)
+    enc = re.search(r"Encrypted top1 acc: (.*)", out.stdout).group(1)
+    assert plain == enc and plain.count(",") == 1
