@@ -42,11 +42,19 @@ def _rgb_batch(n, seed):
     return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed)]).astype(np.float32)
 
 
+def _dct8_112_batch(n, seed):
+    """config #5: 8x8 JPEG-domain DCT, 48 channels, 112x112: Resize(1030) -> CenterCrop(896) -> 8x8 DCT"""
+    from dctfhe import frontend, synthetic
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=112, channels=48)
+    return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed, size=96)]).astype(np.float32)
+
+
 # name -> (model factory name, in_channels, img_size, input batch maker, description)
 CONFIGS = {
     "r20_24_16": ("ResNet20QAT", 24, 16, _dct_batch, "ResNet-20 24x16^2 DCT CIFAR-10 trunk (BASELINE config #2 shape)"),
     "r20_3_32": ("ResNet20QAT", 3, 32, _rgb_batch, "ResNet-20 3x32^2 RGB CIFAR-10 trunk (BASELINE config #3)"),
     "r18_3_32": ("ResNet18QAT", 3, 32, _rgb_batch, "ResNet-18 3x32^2 RGB CIFAR-10 trunk (BASELINE config #4 shape)"),
+    "r18_48_112": ("ResNet18QAT", 48, 112, _dct8_112_batch, "ResNet-18 48x112^2 DCT ImageNet trunk (BASELINE config #5 shape; 16 calibration images)"),
 }
 
 
@@ -121,6 +129,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "4")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tier-policy", default="exact", choices=["exact", "p_error"],
+                    help="exact (the metric): outputs equal the integer circuit; p_error: the reference-style stochastic regime, p_error=0.01 per look-up (speed only)")
+    ap.add_argument("--rounding-method", default="exact", choices=["exact", "approximate"])
     ap.add_argument("--config", default="r20_24_16", choices=sorted(CONFIGS), help="BASELINE.json config; the metric is quoted on r20_24_16")
     args = ap.parse_args()
 
@@ -141,9 +152,10 @@ def main():
     B = args.batch_per_gpu
     # same circuit and same keys on every rank (seed-regenerated: no key traffic)
     factory, in_ch, img, make_batch, workload = CONFIGS[args.config]
-    calib = make_batch(100, 7)
+    calib = make_batch(16 if args.config == "r18_48_112" else 100, 7)
     model = getattr(models, factory)(bit_width=4, in_channels=in_ch, img_size=img, seed=0)
-    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=6, p_error=0.01, device=local_rank)
+    rtb = 6 if args.rounding_method == "exact" else {"n_bits": 6, "method": "approximate"}
+    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=rtb, p_error=0.01, device=local_rank, tier_policy=args.tier_policy)
     t0 = time.time()
     qm.fhe_circuit.keygen(seed=1)
     keygen_s = time.time() - t0
@@ -188,6 +200,7 @@ def main():
     feats_q = qm.decode_output(qm._keys.decrypt(out).reshape(B, -1))
     clear_q = qm.forward_quantized(q, "disable")
     exact = bool(np.array_equal(feats_q, clear_q))
+    diff = np.abs(feats_q.astype(np.int64) - clear_q.astype(np.int64))
     feats = torch.from_numpy(qm.dequantize_output(feats_q)).float()
     logits = feats @ torch.from_numpy(model.classifier_w).float().T + torch.from_numpy(model.classifier_b).float()
     if world > 1:
@@ -237,8 +250,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 torus + f64 FFT",
             "data": "synthetic",
-            "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU, "
-                                   "exact-evaluation tiers, rounding_threshold_bits=6, n_bits=5, bit_width=4",
+            "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU, " +
+                                   ("exact-evaluation tiers" if args.tier_policy == "exact" else "p_error=0.01 tiers (stochastic outputs, speed only)") +
+                                   (", approximate rounding" if args.rounding_method == "approximate" else "") + ", rounding_threshold_bits=6, n_bits=5, bit_width=4",
                        "images_per_gpu": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
                        "s_per_image_per_gpu": elapsed / (B * args.steps),
                        "pbs_per_image": int(sum(stats.pbs_count)), "bit_steps_per_image": int(stats.bit_steps),
@@ -246,7 +260,9 @@ def main():
                        "max_bit_width": int(stats.max_bit_width), "keygen_s": keygen_s,
                        "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes),
                        "images_per_s_pcie_inclusive": images / (elapsed + upload_s * args.steps),
-                       "bit_exact_vs_integer_circuit": exact,
+                       "bit_exact_vs_integer_circuit": exact, "tier_policy": args.tier_policy, "rounding_method": args.rounding_method,
+                       "outputs_equal_frac": float((diff == 0).mean()), "outputs_max_abs_diff": int(diff.max()),
+                       "expected_boundary_flips_per_image": float(getattr(qm.compiled, "expected_boundary_flips_per_image", 0.0)),
                        "predicted_labels": all_logits.argmax(dim=1).tolist(),
                        "expected_table_failures_per_image": qm.compiled.expected_failures_per_image},
             "roofline": {"bound": "hbm", "kernel": f"pbs_kernel<logN={td.logN},k={td.k},l={td.l}> (tier {td.name})",

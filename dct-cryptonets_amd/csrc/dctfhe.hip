@@ -708,7 +708,7 @@ extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, d
       case OP_ADD: s->bytes_algorithmic += 3 * eout * Lb; break;
       case OP_SUMPOOL: s->bytes_algorithmic += (ein + eout) * Lb; break;
       case OP_LUT: {
-        const int r = o.ip[1], tt = o.ip[4], bt = o.ip[5];
+        const int r = o.ip[9] ? 0 : o.ip[1], tt = o.ip[4], bt = o.ip[5];     // approximate rounding: no one-bit steps
         s->lut_sites += (int64_t)ein;
         s->bit_steps += (int64_t)(ein * r);
         s->bytes_algorithmic += 2 * ein * Lb * (1 + r);
@@ -745,7 +745,7 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
     for (size_t i = 0; i < circ->ops.size(); i++) {
       const Op& o = circ->ops[i];
       if (o.type != OP_LUT) continue;
-      const int tt = o.ip[4], bt = o.ip[5], r = o.ip[1], w = o.ip[2];
+      const int tt = o.ip[4], bt = o.ip[5], r = o.ip[9] ? 0 : o.ip[1], w = o.ip[2];
       if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) { delete s; return fail("op %zu names a tier the keys lack", i); }
       if (w > keys->p.tiers[tt].logN - 1) { delete s; return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt); }
       if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) { delete s; return fail("op %zu names a coarse bit tier the keys lack", i); }
@@ -885,11 +885,16 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
           HIPCHK(hipGetLastError());
         } else {
           const int h = tm.begin(CAT_LINEAR);
-          const uint64_t add = body_add + (r > 0 ? (1ULL << (63 - p + r - 1)) : 0);
+          // exact rounding: + half of what is removed, then r one-bit steps clear the low bits.  Approximate rounding
+          // (ip[9], the reference README's {"method": "approximate"}): no steps -- the low bits stay and the half-box
+          // rotation of the test vector does the rounding; + half an input unit puts the two inputs next to a rounding
+          // boundary at equal distance from it (noise beyond that distance gives the neighbouring table entry).
+          const bool approx = o.ip[9] != 0 && r > 0;
+          const uint64_t add = body_add + (approx ? (1ULL << (62 - p)) : (r > 0 ? (1ULL << (63 - p + r - 1)) : 0));
           hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * L)), dim3(256), 0, st, src, dst, E, L, shift, add);
           HIPCHK(hipGetLastError());
           tm.end(h);
-          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
+          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, approx ? 0 : r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
         }
         break;
       }

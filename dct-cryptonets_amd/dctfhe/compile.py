@@ -117,6 +117,8 @@ class CompiledCircuit:
     n_bits: int
     blob: bytes = b""
     expected_failures_per_image: float = 0.0
+    rounding_method: str = "exact"
+    expected_boundary_flips_per_image: float = 0.0    # approximate rounding only
 
     @property
     def e_in(self):
@@ -144,7 +146,7 @@ class CompiledCircuit:
             s = self.tensors[o.src0]
             n = s.C * s.H * s.W
             out[ps.tiers[o.ip[4]].name] = out.get(ps.tiers[o.ip[4]].name, 0) + n
-            if o.r:
+            if o.r and not o.ip[9]:
                 cf = o.ip[8] if (o.ip[7] >= 0 and o.ip[8] < o.r) else o.r
                 fine, coarse = min(cf, o.r), o.r - min(cf, o.r)
                 if fine:
@@ -170,11 +172,14 @@ class CompiledCircuit:
                 head += f" {{k={o.ip[0]}}}"
             elif o.type == OP_LUT:
                 head += (f" {{p={o.p}, lsbs_removed={o.r}, table_bits={o.w}, signed={int(o.signed)}, shift={o.ip[3]}, "
-                         f"tier={ps.tiers[o.ip[4]].name}" + (f", bit_tier={ps.tiers[o.ip[5]].name}" if o.r else "") +
-                         (f", steps>={o.ip[8]}:{ps.tiers[o.ip[7]].name}" if (o.r and o.ip[7] >= 0 and o.ip[8] < o.r) else "") +
+                         f"tier={ps.tiers[o.ip[4]].name}" + (", rounding=approximate" if o.ip[9] else "") +
+                         (f", bit_tier={ps.tiers[o.ip[5]].name}" if (o.r and not o.ip[9]) else "") +
+                         (f", steps>={o.ip[8]}:{ps.tiers[o.ip[7]].name}" if (o.r and not o.ip[9] and o.ip[7] >= 0 and o.ip[8] < o.r) else "") +
                          f", tables={o.ip[6]}, p_fail/elt={o.pfail:.1e}}}  // {o.note}")
             lines.append(f"{head} : [{s.C}x{s.H}x{s.W}] -> [{d.C}x{d.H}x{d.W}] e={d.e}")
         lines.append(f"// expected table failures per image (noise model): {self.expected_failures_per_image:.2e}")
+        if self.rounding_method == "approximate":
+            lines.append(f"// approximate rounding: expected boundary flips per image: {self.expected_boundary_flips_per_image:.2e}")
         return "\n".join(lines)
 
 
@@ -288,11 +293,24 @@ class _Builder:
         return _Act(q, out_scale, tid, lo, hi)
 
 
-def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=None, range_margin=0.05, p_error=None):
+def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=None, range_margin=0.05, p_error=None,
+                  rounding_method="exact", tier_policy="exact"):
     """-> CompiledCircuit.  calib: float [B, C, H, W] calibration inputs (reference: first training batch,
-    homomorphic_eval.py:258-261).  p_error is accepted for signature parity (homomorphic_eval.py:282); the
-    catalogue in dctfhe/params.py is exact-evaluation grade and its failure estimate is reported instead."""
-    ps = param_set or P.default_params()
+    homomorphic_eval.py:258-261).
+    tier_policy "exact" (default): the exact-evaluation catalogue of dctfhe/params.py whatever p_error says (the
+    reference hands p_error = 0.01 to Concrete's optimiser, homomorphic_eval.py:282; here outputs then equal the integer
+    circuit and the modelled failure estimate is reported).  tier_policy "p_error": the cheaper catalogue whose look-ups
+    fail with probability <= p_error each -- stochastic outputs, like the reference's.
+    rounding_method "approximate" (README.md:95-114 of the reference, rounding_threshold_bits={"n_bits":..,"method":
+    "approximate"}): no one-bit rounding steps, the table bootstrap rounds; inputs next to a rounding boundary may land on
+    the neighbouring table entry."""
+    if rounding_method not in ("exact", "approximate"):
+        raise ValueError(f"rounding_method {rounding_method!r}")
+    if tier_policy not in ("exact", "p_error"):
+        raise ValueError(f"tier_policy {tier_policy!r}")
+    if param_set is None:
+        param_set = P.params_for_p_error(p_error if p_error is not None else 0.01) if tier_policy == "p_error" else P.default_params()
+    ps = param_set
     calib = np.asarray(calib, dtype=np.float64)
     bits = model.bit_width
     bld = _Builder(ps, rounding_threshold_bits, range_margin)
@@ -383,7 +401,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
 
     circ = CompiledCircuit(tensors=bld.tensors, ops=bld.ops, input_tensor=t_in, output_tensor=out.tid, in_scale=s_in, in_bits=bits,
                            out_scale=s_f, out_bits=bits, max_bit_width=bld.max_bits, param_set=ps,
-                           rounding_threshold_bits=rounding_threshold_bits, n_bits=n_bits)
+                           rounding_threshold_bits=rounding_threshold_bits, n_bits=n_bits, rounding_method=rounding_method)
     _assign_encodings(circ)
     _estimate_noise(circ)
     circ.blob = _serialize(circ)
@@ -422,6 +440,7 @@ def _assign_encodings(circ):
                 raise ValueError("table wider than the ring")
             o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]
             o.ip[7], o.ip[8] = (ps.bit_tier_coarse if ps.bit_tier_coarse is not None else -1), o.r      # refined by _estimate_noise
+            o.ip[9] = 1 if (circ.rounding_method == "approximate" and o.r > 0) else 0
             o.lp[0] = (1 << 62) if o.signed else 0
             enc = (o.table_values.astype(object) * (1 << T[o.dst].e)) % (1 << 64)
             o.payload = np.array(enc, dtype=np.uint64).view(np.int64)
@@ -435,7 +454,7 @@ def _assign_encodings(circ):
 def _estimate_noise(circ):
     ps, T = circ.param_set, circ.tensors
     T[circ.input_tensor].var = ps.input_sigma ** 2
-    total = 0.0
+    total, flips = 0.0, 0.0
     for o in circ.ops:
         s = T[o.src0]
         n_elt = s.C * s.H * s.W
@@ -450,8 +469,15 @@ def _estimate_noise(circ):
             v_in0 = s.var * 4.0 ** o.ip[3]
             v_tab_in = P.var_keyswitch(ps.D, tt) + P.var_modswitch(tt)
 
+            approx = bool(o.ip[9])
+
             def site_pfail(coarse_from):
                 pf_, v_ = 0.0, v_in0
+                if approx:
+                    # no rounding steps: the low r bits ride along; a failure is noise beyond the half-box.  (The two inputs
+                    # next to a rounding boundary, 2 of 2^r, sit half an input unit from it and take the neighbouring
+                    # entry far more often: the method's own inexactness, reported apart as boundary flips.)
+                    return P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
                 if o.r > 0:
                     bt = ps.tiers[o.ip[5]]
                     v_bit_in = P.var_keyswitch(ps.D, bt) + P.var_modswitch(bt)
@@ -462,18 +488,21 @@ def _estimate_noise(circ):
                 return pf_ + P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
 
             pf = site_pfail(o.r)
-            if o.r > 0 and o.ip[7] >= 0:
+            if o.r > 0 and o.ip[7] >= 0 and not approx:
                 # earliest step from which the one-level bit tier keeps the site within 2x of its all-precise failure rate
-                budget = max(2.0 * pf, 1e-12)
+                budget = max(2.0 * pf, getattr(ps, "p_budget", 1e-12))
                 cf = o.r
                 while cf > 0 and site_pfail(cf - 1) <= budget:
                     cf -= 1
                 o.coarse_from = o.ip[8] = cf
                 pf = site_pfail(cf)
             o.pfail = pf
+            if approx:
+                flips += (2.0 / 2 ** o.r) * P.p_fail(2.0 ** -(o.p + 2), v_in0 + v_tab_in) * n_elt
             total += pf * n_elt
             T[o.dst].var = P.var_pbs_out(tt, ps.fft_noise_c)
     circ.expected_failures_per_image = total
+    circ.expected_boundary_flips_per_image = flips
 
 
 # ------------------------------------------------------------------------------------------ blob

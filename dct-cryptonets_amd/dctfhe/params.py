@@ -59,6 +59,7 @@ class ParamSet:
     coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
     bit_tier_coarse: int = None        # one-level twin of the bit tier for the last rounding steps of a site
     refresh_min_w: int = None          # tables this wide that feed a convolution are split: coarse look-up + small-ring refresh
+    p_budget: float = 1e-12            # failure probability a single look-up site may spend on cheaper rounding steps
     input_sigma: float = 0.0
     fft_noise_c: float = 2.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
 
@@ -140,6 +141,24 @@ def default_params():
     t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
                     coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5)
+
+
+def params_for_p_error(p_error=0.01):
+    """Catalogue for tier_policy "p_error" (SURVEY 8f-4): every look-up may fail with probability ~p_error, the regime the
+    reference runs in (run_homomorphic_eval.sh:26).  z = 2.6 sigma inside the half-box instead of 7, so a 6-bit table fits
+    N = 4096 and a 5-bit one N = 2048; outputs that feed a convolution only have to keep the *next* look-up inside its
+    half-box (sigma ~2^-16 after the 2^6.7 amplification), which two levels with 16-bit digits give (sigma ~2^-21) -- no
+    refresh bootstraps.  Meant for approximate rounding; with exact rounding the one-bit tiers B / Ba serve as before."""
+    if not (1e-6 <= p_error <= 0.05):
+        raise ValueError("tier_policy 'p_error' is meant for 1e-6 <= p_error <= 0.05; use the exact catalogue below that")
+    f6 = TierSpec("F6", n=864, k=1, logN=12, l=2, beta=16, lk=6, betak=3)
+    f5 = TierSpec("F5", n=864, k=1, logN=11, l=2, beta=16, lk=6, betak=3, ksk_share=0)
+    t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0, unroll=2)
+    b = TierSpec("B", n=660, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
+    t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
+    ba = TierSpec("Ba", n=660, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
+    return ParamSet(D=8192, tiers=[f6, f5, t4, b, t5a, ba], bit_tier=3, table_tier_for_w={4: 1, 5: 1, 6: 0},
+                    coarse_tier_for_w={4: 2, 5: 2, 6: 4}, bit_tier_coarse=5, p_budget=p_error / 4.0)
 
 
 def test_params():

@@ -167,17 +167,25 @@ def _as_numpy(t):
 
 
 def compile_brevitas_qat_model(torch_model, torch_inputset, n_bits=5, configuration=None, rounding_threshold_bits=6, p_error=None,
-                               verbose=False, device=0, param_set=None, **kwargs):
+                               verbose=False, device=0, param_set=None, tier_policy="exact", **kwargs):
     """Same keyword surface as the call at reference homomorphic_eval.py:276-285.  `torch_model` is a
-    dctfhe.models.ResNetQ description (Brevitas modules cannot exist here: the package is absent)."""
-    rtb = rounding_threshold_bits["n_bits"] if isinstance(rounding_threshold_bits, dict) else rounding_threshold_bits
+    dctfhe.models.ResNetQ description (Brevitas modules cannot exist here: the package is absent).
+    rounding_threshold_bits: int (exact rounding) or {"n_bits": int, "method": "exact"|"approximate"} as the reference's
+    README.md:95-114 suggests.  tier_policy: "exact" (default, outputs equal the integer circuit whatever p_error) or
+    "p_error" (cheaper tiers whose look-ups fail with probability <= p_error; dctfhe addition)."""
+    method = "exact"
+    if isinstance(rounding_threshold_bits, dict):
+        method = str(rounding_threshold_bits.get("method", "exact")).lower().split(".")[-1]      # also accepts "Exactness.APPROXIMATE"
+        rtb = rounding_threshold_bits["n_bits"]
+    else:
+        rtb = rounding_threshold_bits
     compiled = cc.compile_model(torch_model, _as_numpy(torch_inputset), rounding_threshold_bits=rtb, n_bits=n_bits,
-                                param_set=param_set, p_error=p_error)
+                                param_set=param_set, p_error=p_error, rounding_method=method, tier_policy=tier_policy)
     return QuantizedModule(compiled, device=device, verbose=verbose)
 
 
 def compile_torch_model(torch_model, torch_inputset, n_bits=5, configuration=None, rounding_threshold_bits=6, p_error=None,
-                        verbose=False, device=0, param_set=None, **kwargs):
+                        verbose=False, device=0, param_set=None, tier_policy="exact", **kwargs):
     """PTQ twin of the above (reference homomorphic_eval.py:287-295); the circuit builder is the same."""
     return compile_brevitas_qat_model(torch_model, torch_inputset, n_bits, configuration, rounding_threshold_bits, p_error, verbose,
-                                      device, param_set, **kwargs)
+                                      device, param_set, tier_policy, **kwargs)

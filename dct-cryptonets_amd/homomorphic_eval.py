@@ -53,6 +53,10 @@ def parse_args():
     e = parser.add_argument_group("dctfhe additions")
     e.add_argument("--seed", default=42, type=int, help="seed of the synthetic images")
     e.add_argument("--device", default=0, type=int, help="GPU index")
+    e.add_argument("--rounding_method", default="exact", choices=["exact", "approximate"],
+                   help="exact = the reference's call (int rounding_threshold_bits); approximate = its README's suggested speed-up")
+    e.add_argument("--tier_policy", default="exact", choices=["exact", "p_error"],
+                   help="exact: outputs equal the integer circuit whatever --p_error; p_error: cheaper tiers failing with probability <= --p_error per look-up")
     return parser.parse_args()
 
 
@@ -118,8 +122,9 @@ def main():
     configuration = Configuration(show_progress=False, progress_tag=True, progress_title="Evaluation: ")
     t = time.time()
     compile_fn = compile_brevitas_qat_model if quantization_type == "QAT" else compile_torch_model
-    q_module = compile_fn(model, calib_data, rounding_threshold_bits=params.rounding_threshold_bits, n_bits=params.n_bits, p_error=params.p_error,
-                          configuration=configuration, verbose=params.verbose, device=params.device)
+    rtb = params.rounding_threshold_bits if params.rounding_method == "exact" else {"n_bits": params.rounding_threshold_bits, "method": "approximate"}
+    q_module = compile_fn(model, calib_data, rounding_threshold_bits=rtb, n_bits=params.n_bits, p_error=params.p_error,
+                          configuration=configuration, verbose=params.verbose, device=params.device, tier_policy=params.tier_policy)
     print(f"Time for FHE compilation {time.time() - t:.2f}")
     bitwidth = q_module.fhe_circuit.graph.maximum_integer_bit_width()
     print(f"Max bit-width: {bitwidth} bits" + (" -> it works in FHE!!" if bitwidth <= 16 else " too high for FHE computation"))

@@ -66,3 +66,27 @@ def test_encodings_and_tiers_resnet20():
         assert o.ip[3] >= 0 and c.param_set.tiers[o.ip[4]].logN - 1 >= o.w
     assert c.expected_failures_per_image < 1e-3
     assert "round_lut" in c.report()
+
+
+def test_approximate_rounding_and_p_error_policy(tiny):
+    """approximate rounding drops every one-bit step (flag ip[9] of the blob record) and leaves the integer
+    semantics alone; tier_policy "p_error" switches to the cheaper catalogue with every site within the budget."""
+    from dctfhe import compile as cc, models, params as P
+    from oracle import circuit_ref
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (32, 4, 6, 6))
+    exact = cc.compile_model(models.tiny_resnet_q(), calib, param_set=P.test_params())
+    approx = cc.compile_model(models.tiny_resnet_q(), calib, param_set=P.test_params(), rounding_method="approximate")
+    luts = [o for o in approx.ops if o.type == cc.OP_LUT]
+    assert any(o.r > 0 for o in luts) and all(o.ip[9] == (1 if o.r > 0 else 0) for o in luts)
+    assert all(o.ip[9] == 0 for o in exact.ops if o.type == cc.OP_LUT)
+    assert set(approx.pbs_counts()) == {"t"} and set(exact.pbs_counts()) == {"t", "b"}
+    assert approx.expected_boundary_flips_per_image >= 0.0 and exact.expected_boundary_flips_per_image == 0.0
+    q = cc.act_quant(calib[:3], exact.in_scale, True, exact.in_bits).astype(np.int64)
+    ph = (q.astype(np.uint64) << np.uint64(exact.e_in)).reshape(3, -1)
+    assert np.array_equal(circuit_ref.run_clear(exact.blob, ph)[0], circuit_ref.run_clear(approx.blob, ph)[0])
+    fast = cc.compile_model(models.tiny_resnet_q(), calib, p_error=0.01, tier_policy="p_error", rounding_method="approximate")
+    assert {t.name for t in fast.param_set.tiers} >= {"F6", "F5"}
+    assert max(o.pfail for o in fast.ops if o.type == cc.OP_LUT) <= 0.01
+    with pytest.raises(ValueError):
+        cc.compile_model(models.tiny_resnet_q(), calib, p_error=0.5, tier_policy="p_error")

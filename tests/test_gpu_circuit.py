@@ -73,3 +73,49 @@ def test_cli_mirror_simulate_mode():
     plain = re.search(r"Unencrypted top1 acc: (.*)", out.stdout).group(1)
     enc = re.search(r"Encrypted top1 acc: (.*)", out.stdout).group(1)
     assert plain == enc and plain.count(",") == 1
+
+
+def test_approximate_rounding_small_rings():
+    """rounding_threshold_bits={"n_bits": 6, "method": "approximate"} (reference README.md:95-114): no one-bit steps, the
+    table bootstrap rounds.  The mod-switch noise alone exceeds the half-unit margin of the inputs next to a rounding
+    boundary, so those land on either neighbour: most outputs equal the integer circuit, the rest are a unit or two off."""
+    from dctfhe import models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    qm = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits={"n_bits": 6, "method": "approximate"},
+                                    param_set=P.test_params())
+    try:
+        assert qm.compiled.rounding_method == "approximate" and "rounding=approximate" in qm.fhe_circuit.mlir
+        assert set(qm.compiled.pbs_counts()) == {"t"}                      # table bootstraps only
+        qm.fhe_circuit.keygen(seed=6)
+        q = qm.quantize_input(calib[:5])
+        diff = np.abs(qm.forward_quantized(q, "execute") - _oracle_out(qm, q))
+        print("approximate rounding: exact outputs %.1f%%, max |diff| %d" % (100.0 * (diff == 0).mean(), diff.max()))
+        assert (diff == 0).mean() > 0.5 and diff.max() <= 4
+    finally:
+        qm.close()
+
+
+def test_p_error_tier_policy_full_size_rings():
+    """tier_policy="p_error" + approximate rounding on the small model with the full-size p_error catalogue:
+    stochastic by design -- most outputs equal the integer circuit, the rest are a few units off (boundary flips of the
+    6-bit rounding propagate through the residual blocks)."""
+    from dctfhe import models
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    qm = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits={"n_bits": 6, "method": "approximate"},
+                                    p_error=0.01, tier_policy="p_error")
+    try:
+        names = set(qm.compiled.pbs_counts())
+        assert names <= {"F6", "F5", "T4", "T5a"} and "F6" in names
+        assert max(o.pfail for o in qm.compiled.ops if o.type == 4) <= 0.01
+        qm.fhe_circuit.keygen(seed=8)
+        q = qm.quantize_input(calib[:4])
+        got, want = qm.forward_quantized(q, "execute"), _oracle_out(qm, q)
+        diff = np.abs(got - want)
+        print("p_error policy: exact outputs %.1f%%, max |diff| %d" % (100.0 * (diff == 0).mean(), diff.max()))
+        assert (diff == 0).mean() > 0.5 and diff.max() <= 4
+    finally:
+        qm.close()
