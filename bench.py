@@ -122,7 +122,20 @@ def cpu_baseline(qm, stats, n_prime=16):
                 s_per_image=total_s, per_tier=detail)
 
 
+def _heartbeat(period=60.0):
+    """one stderr line a minute: a long encrypted run (config #5 takes ~12 min) must not look hung to the job runner"""
+    import threading
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(period)
+            print(f"[bench] running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
 def main():
+    _heartbeat()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)

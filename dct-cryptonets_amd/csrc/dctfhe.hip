@@ -247,8 +247,8 @@ static int check_params(const dctfhe_params* p) {
     const dctfhe_tier& t = p->tiers[i];
     if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
     if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
-    if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 31))
-      return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 31 when l == 1)", i);
+    if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 28))
+      return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 28 when l == 1: 32-bit accumulators)", i);
     if (t.unroll != 1 && t.unroll != 2) return fail("tier %d: unroll must be 1 or 2", i);
     if (t.unroll == 2 && (t.k != 1 || t.l != 1 || t.logN < 11 || (t.n & 1))) return fail("tier %d: unroll 2 needs k = 1, l = 1, N >= 2048, n even", i);
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);

@@ -40,6 +40,11 @@ namespace dctfhe {
 #define PBS_PAIR 1
 #endif
 
+// one-level tiers keep the accumulator as 32-bit torus values (see pbs_geom::ACC32)
+#ifndef PBS_ACC32
+#define PBS_ACC32 1
+#endif
+
 #ifndef PBS_PF_DIST
 #define PBS_PF_DIST 2
 #endif
@@ -71,7 +76,14 @@ struct pbs_geom {
   static constexpr int NG = P / RL;                    // small transforms per thread in the last pass
   static constexpr int NL_AUTO = (K >= 2 || L >= 3) ? 1 : 0;
   static constexpr int NL = PBS_LDS_POLYS < 0 ? NL_AUTO : (PBS_LDS_POLYS < K ? PBS_LDS_POLYS : K);
-  static constexpr int STAGE_BYTES = N * 8;
+  // ACC32: a one-level gadget rounds every accumulator coefficient to 2^-(beta+1) >= 2^-29 of the torus at each step anyway
+  // (beta <= 28 enforced by the library for such tiers), so the accumulator of a one-level tier is kept as the top 32 bits:
+  // the rounding of each update (2^-33) is far below that, the registers and the LDS traffic of the rotation halve, and
+  // the f64 -> torus conversion drops from 8+3 to 5+1 instructions.  Multi-level tiers (convolution-grade outputs) keep 64.
+  static constexpr bool ACC32 = PBS_ACC32 && L == 1;
+  using acc_t = std::conditional_t<ACC32, uint32_t, uint64_t>;
+  static constexpr int ACC_BYTES = (int)sizeof(acc_t);
+  static constexpr int STAGE_BYTES = N * ACC_BYTES;
   static constexpr int EXCH_BYTES = F::EXCH_ELEMS * 16;
   // the stage only aliases the exchange buffer when an LDS-resident polynomial needs the room: aliasing costs one
   // extra barrier per register polynomial and iteration (measured -3% on the one-level N = 8192 kernel)
@@ -79,7 +91,7 @@ struct pbs_geom {
   static_assert(!PAIR || (NL == 0 && EXCH_BYTES >= STAGE_BYTES), "pair mode stages each polynomial in its exchange buffer");
   static constexpr int STAGE_OFFSET = ALIAS ? 0 : EXCH_BYTES;
   static constexpr int SHARED_BYTES = PAIR ? 2 * EXCH_BYTES : MB ? EXCH_BYTES /* no rotation stage */ : ALIAS ? (EXCH_BYTES > STAGE_BYTES ? EXCH_BYTES : STAGE_BYTES) : EXCH_BYTES + STAGE_BYTES;
-  static constexpr int ACCL_BYTES = NL * N * 8;
+  static constexpr int ACCL_BYTES = NL * N * ACC_BYTES;
   static constexpr int GROUP_BYTES = SHARED_BYTES + ACCL_BYTES;
   // twiddle table in LDS, shared by all groups of a workgroup; the pair kernels of the two big rings are short of
   // LDS and leave the T twist bases in global memory (read once per bootstrap)
@@ -109,6 +121,17 @@ HD void decompose(uint64_t v, int beta, int32_t* digs) {
     });
   }
 }
+
+// one level from a 32-bit accumulator word
+template <int L>
+HD void decompose(uint32_t v, int beta, int32_t* digs) {
+  static_assert(L == 1, "32-bit accumulators are for one-level tiers");
+  digs[0] = (int32_t)(v + (1u << (31 - beta))) >> (32 - beta);
+}
+HD void acc_add(uint64_t& a, double d) { a += f64_to_torus(d); }
+HD void acc_add(uint32_t& a, double d) { a += f64_to_torus32(d); }
+HD uint64_t acc_wide(uint64_t a) { return a; }
+HD uint64_t acc_wide(uint32_t a) { return (uint64_t)a << 32; }
 
 // test-vector coefficient j (0 <= j < N) of the table T (2^w entries)
 HD uint64_t testvec_coeff(const int64_t* table, int w, int N, int j) {
@@ -153,9 +176,12 @@ struct pbs_args {
 // factor zeta^e, zeta = e^{i pi (1-4k)/N} the evaluation point (spectrum_freq).  Price: three key blocks per pair
 // instead of two, and the key/FFT noise of three products scaled by |X^e - 1|^2 = 2 (dctfhe/params.py prices it).
 template <int LOGN, int K, int L, int P, int MB = 0, class Sync, class WSync>
-HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cplx* exch, uint64_t* accl, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
+HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw, cplx* exch, uint64_t* accl_raw, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
+  using acc_t = typename G::acc_t;
+  acc_t* const stage = reinterpret_cast<acc_t*>(stage_raw);
+  acc_t* const accl = reinterpret_cast<acc_t*>(accl_raw);
   const int n = A.n;
   const int msh = 64 - LOGN - 2;
   const cplx twist = A.twist[t];
@@ -172,7 +198,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
     if (line < 0) line = 0;
     pf_ptr = reinterpret_cast<const char*>(A.bsk + (size_t)PBS_PF_DIST * G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT) + (size_t)line * 128;
   }
-  uint64_t acc[K + 1][2 * P];
+  acc_t acc[K + 1][2 * P];
   {  // ACC = X^{-b~} * TV (trivial GLWE)
     const uint32_t bt = (uint32_t)(((A.ct_small[n] >> msh) + 1) >> 1) & (2 * N - 1);
     static_for<0, K>([&](auto Pp) {
@@ -187,7 +213,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       constexpr int r = decltype(R)::value;
       const uint32_t idx = ((uint32_t)(t + T * r) + bt) & (2 * N - 1);
       const uint64_t v = testvec_coeff(A.table, A.w, N, (int)(idx & (N - 1)));
-      acc[K][r] = (idx & N) ? (uint64_t)0 - v : v;
+      acc[K][r] = (acc_t)(((idx & N) ? (uint64_t)0 - v : v) >> (64 - 8 * G::ACC_BYTES));
     });
   }
 
@@ -219,7 +245,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         double first[2 * P];
         static_for<0, 2 * P>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          uint64_t own;
+          acc_t own;
           if constexpr (p < NL) own = accl[p * N + t + T * r]; else own = acc[p][r];
           int32_t dg[L];
           decompose<L>(own, A.beta, dg);
@@ -337,7 +363,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       // both accumulator polynomials go through their stages at once (stage p = exchange buffer p; everybody is past
       // the last gather of the previous inverse transforms: their trailing barrier), one barrier, then the rotated
       // reads; the leading barrier of the forward transforms covers those reads.
-      constexpr int EX = G::F::EXCH_ELEMS * 2;   // u64 words per exchange buffer
+      constexpr int EX = G::F::EXCH_ELEMS * (16 / G::ACC_BYTES);   // accumulator words per exchange buffer
       static_for<0, 2>([&](auto Pp) {
         constexpr int p = decltype(Pp)::value;
         static_for<0, 2 * P>([&](auto R) { constexpr int r = decltype(R)::value; stage[p * EX + t + T * r] = acc[p][r]; });
@@ -349,10 +375,10 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
         static_for<0, 2 * P>([&](auto R) {
           constexpr int r = decltype(R)::value;
           const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
-          const uint64_t x = stage[p * EX + (src & (N - 1))];
-          const uint64_t m = (uint64_t)0 - (uint64_t)((src >> LOGN) & 1);      // all ones where the rotation wraps: -x = (x ^ m) - m
+          const acc_t x = stage[p * EX + (src & (N - 1))];
+          const acc_t m = (acc_t)0 - (acc_t)((src >> LOGN) & 1);      // all ones where the rotation wraps: -x = (x ^ m) - m
           int32_t dg[1];
-          decompose<1>((x ^ m) - m - acc[p][r], A.beta, dg);
+          decompose<1>((acc_t)((x ^ m) - m - acc[p][r]), A.beta, dg);
           if constexpr (r < P) v[p][r].re = (double)dg[0]; else v[p][r - P].im = (double)dg[0];
         });
       });
@@ -404,12 +430,12 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       static_for<0, 2 * P>([&](auto R) {
         constexpr int r = decltype(R)::value;
         const uint32_t src = ((uint32_t)(t + T * r) - a) & (2 * N - 1);
-        uint64_t x, own;
+        acc_t x, own;
         if constexpr (p < NL) { x = accl[p * N + (src & (N - 1))]; own = accl[p * N + t + T * r]; }
         else                  { x = stage[src & (N - 1)]; own = acc[p][r]; }
-        if (src & N) x = (uint64_t)0 - x;     // (a branch-free (x ^ m) - m here makes hipcc spill 200+ bytes more per lane)
+        if (src & N) x = (acc_t)0 - x;     // (a branch-free (x ^ m) - m here makes hipcc spill 200+ bytes more per lane)
         int32_t dg[L];
-        decompose<L>(x - own, A.beta, dg);
+        decompose<L>((acc_t)(x - own), A.beta, dg);
         first[r] = (double)dg[0];
         uint32_t pk = 0;
         if constexpr (L > 1) pk = (uint32_t)(uint16_t)(int16_t)dg[1];
@@ -477,11 +503,11 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       static_for<0, P>([&](auto J) {
         constexpr int j = decltype(J)::value;
         if constexpr (q < NL) {
-          accl[q * N + t + T * j] += f64_to_torus(out[q][j].re);
-          accl[q * N + t + T * (P + j)] += f64_to_torus(out[q][j].im);
+          acc_add(accl[q * N + t + T * j], out[q][j].re);
+          acc_add(accl[q * N + t + T * (P + j)], out[q][j].im);
         } else {
-          acc[q][j] += f64_to_torus(out[q][j].re);
-          acc[q][P + j] += f64_to_torus(out[q][j].im);
+          acc_add(acc[q][j], out[q][j].re);
+          acc_add(acc[q][P + j], out[q][j].im);
         }
       });
     });
@@ -496,7 +522,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
       const int c = t + T * r;
       const int dst = p * N + (c == 0 ? 0 : N - c);
       uint64_t av;
-      if constexpr (p < NL) av = accl[p * N + c]; else av = acc[p][r];
+      if constexpr (p < NL) av = acc_wide(accl[p * N + c]); else av = acc_wide(acc[p][r]);
       const uint64_t v = (c == 0) ? av : (uint64_t)0 - av;
       if (A.accumulate) o[dst] += v; else o[dst] = v;
     });
@@ -504,7 +530,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage, cp
   if (!A.accumulate)
     for (int j = K * N + t; j < A.D_out; j += T) o[j] = 0;
   if (t == 0) {
-    if (A.accumulate) o[A.D_out] += acc[K][0] + A.body_add; else o[A.D_out] = acc[K][0] + A.body_add;
+    if (A.accumulate) o[A.D_out] += acc_wide(acc[K][0]) + A.body_add; else o[A.D_out] = acc_wide(acc[K][0]) + A.body_add;
   }
 }
 
