@@ -144,8 +144,104 @@ static int fft_case() {
   return err > 1e-6 || serr > 1e-3;
 }
 
+// ---- the integer/f64 helpers the kernels lean on, against independent definitions
+static int torus_case() {     // f64 -> torus: the integer nearest to d, mod 2^64 (and its top 32 bits), |d| < 2^116
+  uint64_t st = 5; int bad = 0;
+  for (int it = 0; it < 4000000; it++) {
+    const int e = (int)(ref_splitmix64(&st) % 118) - 2;
+    double d = std::ldexp((double)(int64_t)ref_splitmix64(&st) / 9223372036854775808.0, e);
+    if (it % 7 == 0) d = std::nearbyint(d) + ((it % 3) ? 0.0 : 0.5);
+    const double r = std::nearbyint(d);
+    uint64_t want = 0;
+    if (r != 0) {
+      int ex; const double m = std::frexp(r, &ex);
+      const __int128 mant = (__int128)std::ldexp(m, 53);
+      const bool neg = mant < 0; const unsigned __int128 a = neg ? (unsigned __int128)(-mant) : (unsigned __int128)mant;
+      const int sh = ex - 53;
+      const unsigned __int128 v = sh >= 0 ? (sh >= 128 ? 0 : a << sh) : a >> (-sh);
+      want = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    }
+    if (f64_to_torus(d) != want) bad++;
+    // top half: round(d / 2^32) mod 2^32 -- differs from want >> 32 only by the carry of the rounding
+    const uint32_t t32 = f64_to_torus32(d), lo = (uint32_t)(want >> 32);
+    if (t32 != lo && t32 != lo + 1u) bad++;
+  }
+  std::printf("f64_to_torus: %d mismatches\n", bad);
+  return bad != 0;
+}
+template <int L> static int decompose_one(int beta) {
+  uint64_t st = beta * 7 + L; int bad = 0;
+  for (int it = 0; it < 1000000; it++) {
+    uint64_t v = ref_splitmix64(&st);
+    if (it % 5 == 0) v |= ~0ULL << (it % 64);
+    if (it % 11 == 0) v = ~0ULL - (ref_splitmix64(&st) & 0xffff);
+    int32_t a[L], b[L];
+    decompose<L>(v, beta, a); ref_decompose(v, L, beta, b);
+    for (int i = 0; i < L; i++) bad += a[i] != b[i];
+    if constexpr (L == 1) { int32_t c[1]; decompose<1>((uint32_t)(v >> 32), beta, c); bad += c[0] != b[0]; }
+  }
+  return bad;
+}
+static int decompose_case() {
+  const int bad = decompose_one<1>(22) + decompose_one<1>(23) + decompose_one<1>(28) + decompose_one<1>(7) + decompose_one<2>(14) +
+                  decompose_one<2>(16) + decompose_one<3>(11) + decompose_one<3>(12) + decompose_one<2>(5);
+  std::printf("decompose vs oracle: %d mismatches\n", bad);
+  return bad != 0;
+}
+// spectrum_freq: the transform of the polynomial X puts e^{i pi (1 - 4k)/N} at position p, k = spectrum_freq(p);
+// fft_forward_n / fft_inverse_n: bit-identical to separate transforms
+template <int LOGN, int P> static int layout_case() {
+  constexpr int N = 1 << LOGN, M = N / 2; using F = fft_geom<LOGN - 1, P>; constexpr int T = F::T;
+  std::vector<cplx> tw(F::TW_ELEMS), ex2(2 * F::EXCH_ELEMS), ex1(F::EXCH_ELEMS), spec(M), a(2 * M), b(2 * M), ia(2 * M), ib(2 * M);
+  fill_twiddles<LOGN - 1, P>(tw.data());
+  std::vector<double> x(2 * N);
+  for (int i = 0; i < 2 * N; i++) x[i] = (double)((i * 2654435761u) % 1000) - 500;
+  std::barrier bar(T);
+  auto worker = [&](int t) {
+    auto sync = [&] { bar.arrive_and_wait(); };
+    const cplx twist = tw[F::TW_TOTAL + t];
+    cplx v1[P];
+    for (int j = 0; j < P; j++) v1[j] = cmk((t + T * j) == 1 ? 1.0 : 0.0, 0.0);
+    fft_forward<LOGN - 1, P>(v1, t, tw.data(), twist, ex1.data(), sync, sync);
+    for (int j = 0; j < P; j++) spec[P * t + j] = v1[j];
+    sync();
+    cplx v[2][P];
+    for (int u = 0; u < 2; u++) for (int j = 0; j < P; j++) v[u][j] = cmk(x[u * N + t + T * j], x[u * N + t + T * j + M]);
+    fft_forward_n<LOGN - 1, P, 2>(v, t, tw.data(), twist, ex2.data(), sync, sync);
+    for (int u = 0; u < 2; u++) for (int j = 0; j < P; j++) a[u * M + j * T + t] = v[u][j];
+    fft_inverse_n<LOGN - 1, P, 2>(v, t, tw.data(), twist, ex2.data(), sync, sync);
+    for (int u = 0; u < 2; u++) for (int j = 0; j < P; j++) ia[u * M + j * T + t] = v[u][j];
+    for (int u = 0; u < 2; u++) {
+      cplx w[P];
+      for (int j = 0; j < P; j++) w[j] = cmk(x[u * N + t + T * j], x[u * N + t + T * j + M]);
+      fft_forward<LOGN - 1, P>(w, t, tw.data(), twist, ex1.data(), sync, sync);
+      for (int j = 0; j < P; j++) b[u * M + j * T + t] = w[j];
+      fft_inverse<LOGN - 1, P>(w, t, tw.data(), twist, ex1.data(), sync, sync);
+      for (int j = 0; j < P; j++) ib[u * M + j * T + t] = w[j];
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+  for (auto& z : th) z.join();
+  double err = 0; int bad = 0;
+  const double PI = 3.14159265358979323846;
+  for (int p = 0; p < M; p++) {
+    const double ang = PI * (1.0 - 4.0 * spectrum_freq<LOGN - 1, P>(p)) / N;
+    err = std::fmax(err, std::hypot(spec[p].re - std::cos(ang), spec[p].im - std::sin(ang)));
+  }
+  for (int i = 0; i < 2 * M; i++) bad += (a[i].re != b[i].re) + (a[i].im != b[i].im) + (ia[i].re != ib[i].re) + (ia[i].im != ib[i].im);
+  std::printf("layout N=%d P=%d: spectrum_freq err=%.3g, interleaved-vs-single mismatches=%d\n", N, P, err, bad);
+  return err > 1e-9 || bad != 0;
+}
+
 int main() {
   int fail = 0;
+  fail |= torus_case();
+  fail |= decompose_case();
+  fail |= layout_case<9, 8>();
+  fail |= layout_case<10, 8>();
+  fail |= layout_case<11, 8>();
+  fail |= layout_case<12, 8>();
   fail |= fft_case<8, 16>();
   fail |= fft_case<9, 8>();
   fail |= fft_case<9, 16>();
