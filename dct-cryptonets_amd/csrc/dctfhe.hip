@@ -52,7 +52,8 @@ struct dctfhe_ctx {
 struct TierKeys {
   dctfhe_tier t{};
   uint64_t* d_ksk = nullptr;     // [D][lk][n+1]
-  uint64_t* d_colsum = nullptr;  // [n+1]
+  uint64_t* d_colsum = nullptr;  // [n+1], over all D*lk rows
+  std::map<int, uint64_t*>* colsum_eff = nullptr;   // column sums over the first Deff*lk rows (shared with the key's owner)
   int8_t* d_kskT = nullptr;      // signed byte limbs, [8(n+1) padded to 128][D*lk], for the MFMA key switch
   int ncol_pad = 0;
   bool own_ksk = false;
@@ -301,7 +302,9 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
       tk.d_colsum = K->tiers[t.ksk_share].d_colsum;
       tk.d_kskT = K->tiers[t.ksk_share].d_kskT;
       tk.ncol_pad = K->tiers[t.ksk_share].ncol_pad;
+      tk.colsum_eff = K->tiers[t.ksk_share].colsum_eff;
     } else {
+      tk.colsum_eff = new std::map<int, uint64_t*>();
       const size_t rows = (size_t)D * t.lk;
       HIPCHK(hipMalloc(&tk.d_ksk, rows * (t.n + 1) * 8));
       HIPCHK(hipMalloc(&tk.d_colsum, (size_t)(t.n + 1) * 8));
@@ -361,7 +364,10 @@ extern "C" int dctfhe_keys_destroy(dctfhe_keys* K) {
   hipSetDevice(K->ctx->device);
   hipFree(K->d_S); hipFree(K->d_s); hipFree(K->d_dummy);
   for (int i = 0; i < K->p.n_tiers; i++) {
-    if (K->tiers[i].own_ksk) { hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); if (K->tiers[i].d_kskT) hipFree(K->tiers[i].d_kskT); }
+    if (K->tiers[i].own_ksk) {
+      hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); if (K->tiers[i].d_kskT) hipFree(K->tiers[i].d_kskT);
+      if (K->tiers[i].colsum_eff) { for (auto& kv : *K->tiers[i].colsum_eff) hipFree(kv.second); delete K->tiers[i].colsum_eff; }
+    }
     hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw); hipFree(K->tiers[i].d_wtab); hipFree(K->tiers[i].d_spair);
   }
   delete K;
@@ -448,19 +454,34 @@ struct Timers {
 enum { CAT_LINEAR = 100, CAT_KS = 101 };  // 0..7: bootstrap of tier i
 
 // key switch of `count` ciphertexts (D+1 words each) into small ciphertexts of tier `tier`
+// deff: mask words beyond it are known to be zero in every input (0 or >= D: no such knowledge).  The key switch then
+// runs on the first deff rows of the key only -- the same result bit for bit, deff/D of the work.
 static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t count, int shift, uint8_t* d_digits, uint64_t* d_bodies,
-                         uint64_t* d_small, Timers* tm) {
+                         uint64_t* d_small, Timers* tm, int deff = 0) {
   const dctfhe_tier& t = K->p.tiers[tier];
-  const TierKeys& tk = K->tiers[tier];
+  TierKeys& tk = K->tiers[tier];
   const int D = K->p.D;
   hipStream_t st = K->ctx->stream;
+  int De = (deff > 0 && deff < D && tk.d_kskT && (deff * t.lk) % 64 == 0) ? deff : D;
+  const uint64_t* colsum = tk.d_colsum;
+  if (De < D) {
+    auto it = tk.colsum_eff->find(De);
+    if (it == tk.colsum_eff->end()) {
+      uint64_t* cs = nullptr;
+      HIPCHK(hipMalloc(&cs, (size_t)(t.n + 1) * 8));
+      hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, De * t.lk, t.n, cs);
+      HIPCHK(hipGetLastError());
+      it = tk.colsum_eff->emplace(De, cs).first;
+    }
+    colsum = it->second;
+  }
   const int h = tm ? tm->begin(CAT_KS) : -1;
-  const size_t total = count * (size_t)D;
+  const size_t total = count * (size_t)De;
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
-  hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, D, shift, t.lk, t.betak, d_digits, d_bodies);
+  hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, D, De, shift, t.lk, t.betak, d_digits, d_bodies);
   if (tk.d_kskT) {   // matrix-core path: i8 digits x signed byte limbs of the key
     dim3 g2((unsigned)(tk.ncol_pad / 128), (unsigned)((count + 127) / 128));
-    hipLaunchKernelGGL(k_ks_mfma, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_kskT, tk.d_colsum, t.n, t.betak, d_small);
+    hipLaunchKernelGGL(k_ks_mfma, g2, dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, colsum, t.n, t.betak, d_small);
   } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64): integer VALU GEMM
     constexpr int CT = 16;
     dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));
@@ -486,11 +507,11 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
 }
 
 static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t L, const int8_t* d_w, int Cout, int KH,
-                      int KW, int stride, int pad, uint64_t* out) {
+                      int KW, int stride, int pad, uint64_t* out, size_t deff = 0) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   constexpr int COT = 16;
   dim3 grid((unsigned)((L + 255) / 256), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + COT - 1) / COT));
-  hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, L, d_w, Cout, KH, KW, stride, pad, Ho, Wo, out);
+  hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, L, (deff > 0 && deff < L - 1) ? deff : L - 1, d_w, Cout, KH, KW, stride, pad, Ho, Wo, out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -501,18 +522,21 @@ static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::mi
 struct LutScratch { uint8_t* digits; uint64_t* bodies; uint64_t* small; int64_t* bit_tables; size_t chunk; };
 // rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe)
 static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, uint64_t* d_work, size_t count, int p, int r,
-                         const int64_t* d_tables, int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm) {
+                         const int64_t* d_tables, int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm, int deff = 0) {
   const size_t L = (size_t)K->p.D + 1;
+  // the rounding steps add bit-tier outputs (dimension k*N of that tier) to the working ciphertexts
+  auto ring = [&](int tier) { return tier >= 0 ? (K->p.tiers[tier].k << K->p.tiers[tier].logN) : 0; };
+  if (deff > 0 && r > 0) deff = std::max(deff, std::max(ring(bit_tier), coarse_from < r ? ring(bit_tier_coarse) : 0));
   for (size_t c0 = 0; c0 < count; c0 += sc.chunk) {
     const size_t cn = std::min(sc.chunk, count - c0);
     uint64_t* w0 = d_work + c0 * L;
     for (int i = 0; i < r; i++) {
       const int bt = (bit_tier_coarse >= 0 && i >= coarse_from) ? bit_tier_coarse : bit_tier;
-      CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm));
+      CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm, deff));
       const int vlog = 62 - p + i;
       CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm));
     }
-    CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm));
+    CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm, deff));
     CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm));
   }
   return 0;
@@ -855,7 +879,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
     switch (o.type) {
       case OP_CONV: {
         const int h = tm.begin(CAT_LINEAR);
-        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, L, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst));
+        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, L, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst, K ? (size_t)o.ip[10] : 0));
         tm.end(h);
         break;
       }
@@ -894,7 +918,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
           hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * L)), dim3(256), 0, st, src, dst, E, L, shift, add);
           HIPCHK(hipGetLastError());
           tm.end(h);
-          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, approx ? 0 : r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm));
+          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, approx ? 0 : r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm, o.ip[10]));
         }
         break;
       }

@@ -164,19 +164,21 @@ k_bsk_fourier(const uint64_t* __restrict__ polys, size_t npoly, const cplx* __re
 // ------------------------------------------------------------------------------------------ K3 key switch
 // Step 1: digits of (ct << shift) for every mask word, offset to unsigned: dig' = dig + B/2 in [0,B).
 // Layout digits[c][i*lk + lev] (u8).  Also copies the (shifted) body.
-__global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, int D, int shift, int lk, int betak,
+// Only the first Deff mask words are decomposed (digits [count][Deff*lk]): the caller knows the rest to be zero (nested
+// keys: a ciphertext that came out of a ring of dimension kN <= Deff has a zero tail), and a zero word contributes nothing.
+__global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, int D, int Deff, int shift, int lk, int betak,
                                uint8_t* __restrict__ digits, uint64_t* __restrict__ bodies) {
-  const size_t total = count * (size_t)D;
+  const size_t total = count * (size_t)Deff;
   const int half = 1 << (betak - 1);
   for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
-    const size_t c = x / D;
-    const int i = (int)(x % D);
+    const size_t c = x / Deff;
+    const int i = (int)(x % Deff);
     const uint64_t v = cts[c * (size_t)(D + 1) + i] << shift;
     const int tot = lk * betak;
     uint64_t xx = (v + (1ULL << (63 - tot))) >> (64 - tot);
     const uint64_t B = 1ULL << betak, mask = B - 1;
     uint64_t carry = 0;
-    uint8_t* dst = digits + (c * (size_t)D + i) * lk;
+    uint8_t* dst = digits + (c * (size_t)Deff + i) * lk;
     for (int lev = lk - 1; lev >= 0; lev--) {
       uint64_t d = (xx & mask) + carry;
       xx >>= betak;
@@ -255,8 +257,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // (2 x 2 MFMA tiles).  Both operands are K-contiguous, so a lane's 16-byte fragment is one ds_read_b128 and
 // the A and B fragments of a lane cover the same 16 k's whatever order the hardware walks them in.
 __global__ void __launch_bounds__(256)
-k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R, const int8_t* __restrict__ kskT,
-          const uint64_t* __restrict__ colsum, int n, int betak, uint64_t* __restrict__ out) {
+k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R /* rows used: Deff*lk */,
+          const int8_t* __restrict__ kskT, int ldk /* row stride of kskT: D*lk */, const uint64_t* __restrict__ colsum /* over the R rows used */,
+          int n, int betak, uint64_t* __restrict__ out) {
   constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 16;     // +16 B per row: rows land on different bank groups
   __shared__ __attribute__((aligned(16))) int8_t As[BM * LD];
   __shared__ __attribute__((aligned(16))) int8_t Bs[BN * LD];
@@ -280,7 +283,7 @@ k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
     size_t c = c0 + srow + 64 * u;
     if (c >= count) c = count - 1;
     a_src[u] = digits + c * (size_t)R + sseg;
-    b_src[u] = kskT + (col0 + srow + 64 * u) * (size_t)R + sseg;
+    b_src[u] = kskT + (col0 + srow + 64 * u) * (size_t)ldk + sseg;
   }
   const int fr = lane & 31, fh = (lane >> 5) * 16;
   for (int k0 = 0; k0 < R; k0 += BK) {
@@ -415,7 +418,7 @@ pbs_kernel(pbs_launch a) {
 // words, so every load is a coalesced stream of one input ciphertext.
 template <int COT>
 __global__ void __launch_bounds__(256)
-k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1 */, const int8_t* __restrict__ wgt, int Cout,
+k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1 */, size_t Deff, const int8_t* __restrict__ wgt, int Cout,
          int KH, int KW, int stride, int pad, int Ho, int Wo, uint64_t* __restrict__ out) {
   const size_t word = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int pix = blockIdx.y;           // b*Ho*Wo + y*Wo + x
@@ -425,6 +428,14 @@ k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1
   uint64_t acc[COT];
 #pragma unroll
   for (int c = 0; c < COT; c++) acc[c] = 0;
+  if (word >= Deff && word != L - 1) {   // mask words every input has at zero: write the zeros, read nothing (wave-uniform but for one wave)
+#pragma unroll
+    for (int c = 0; c < COT; c++) {
+      const int co = co0 + c;
+      if (co < Cout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * L + word] = 0;
+    }
+    return;
+  }
   const uint64_t* inb = in + (size_t)b * Cin * H * W * L;
   for (int ci = 0; ci < Cin; ci++)
     for (int ky = 0; ky < KH; ky++) {

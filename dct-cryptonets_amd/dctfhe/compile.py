@@ -78,6 +78,7 @@ class TensorInfo:
     lo: int = 0
     hi: int = 0              # guaranteed (tables) or calibrated (accumulators) value range
     var: float = 0.0         # noise variance estimate (torus^2)
+    deff: int = 0            # mask words beyond this index are zero (nested keys: a bootstrap output of ring k*N has a zero tail)
 
 
 @dataclass
@@ -421,6 +422,7 @@ def _assign_encodings(circ):
         for s in ([o.src0, o.src1] if o.type == OP_ADD else [o.src0]):
             req[s] = need if req[s] is None else min(req[s], need)
     T[circ.input_tensor].e = req[circ.input_tensor]
+    T[circ.input_tensor].deff = circ.param_set.D
     # a table whose output is only ever added (or decrypted) tolerates a noisier, cheaper tier
     amplified = [False] * len(T)
     for o in ops:
@@ -441,11 +443,15 @@ def _assign_encodings(circ):
             o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]
             o.ip[7], o.ip[8] = (ps.bit_tier_coarse if ps.bit_tier_coarse is not None else -1), o.r      # refined by _estimate_noise
             o.ip[9] = 1 if (circ.rounding_method == "approximate" and o.r > 0) else 0
+            o.ip[10] = T[o.src0].deff
+            T[o.dst].deff = ps.tiers[tier].k << ps.tiers[tier].logN
             o.lp[0] = (1 << 62) if o.signed else 0
             enc = (o.table_values.astype(object) * (1 << T[o.dst].e)) % (1 << 64)
             o.payload = np.array(enc, dtype=np.uint64).view(np.int64)
         else:
             T[o.dst].e = T[o.src0].e
+            T[o.dst].deff = max(T[o.src0].deff, T[o.src1].deff) if o.type == OP_ADD else T[o.src0].deff
+            o.ip[10] = T[o.dst].deff
             if o.type == OP_ADD:
                 assert T[o.src1].e == T[o.src0].e, "residual operands must share an encoding"
 
@@ -467,7 +473,8 @@ def _estimate_noise(circ):
         else:
             tt = ps.tiers[o.ip[4]]
             v_in0 = s.var * 4.0 ** o.ip[3]
-            v_tab_in = P.var_keyswitch(ps.D, tt) + P.var_modswitch(tt)
+            d_in = s.deff or ps.D                                     # the key switch only sums over the non-zero mask words
+            v_tab_in = P.var_keyswitch(d_in, tt) + P.var_modswitch(tt)
 
             approx = bool(o.ip[9])
 
@@ -480,7 +487,7 @@ def _estimate_noise(circ):
                     return P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
                 if o.r > 0:
                     bt = ps.tiers[o.ip[5]]
-                    v_bit_in = P.var_keyswitch(ps.D, bt) + P.var_modswitch(bt)
+                    v_bit_in = P.var_keyswitch(max(d_in, bt.k << bt.logN), bt) + P.var_modswitch(bt)
                     for i in range(o.r):
                         pf_ += P.p_fail(0.25, 4.0 ** (o.p - i) * v_ + v_bit_in)
                         step_tier = ps.tiers[o.ip[7]] if (i >= coarse_from and o.ip[7] >= 0) else bt
