@@ -244,6 +244,7 @@ extern "C" int dctfhe_ctx_synchronize(dctfhe_ctx* c) {
 static int check_params(const dctfhe_params* p) {
   if (p->n_tiers < 1 || p->n_tiers > DCTFHE_MAX_TIERS) return fail("n_tiers out of range");
   if (p->D < 4 || p->D % 4) return fail("D must be a positive multiple of 4");
+  if (p->input_dim < 0 || p->input_dim > p->D) return fail("input_dim out of range");
   for (int i = 0; i < p->n_tiers; i++) {
     const dctfhe_tier& t = p->tiers[i];
     if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
@@ -412,7 +413,7 @@ extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* p
   HIPCHK(hipMalloc(&d_ph, count * 8));
   HIPCHK(hipMalloc(&d_ct, count * (size_t)(D + 1) * 8));
   HIPCHK(hipMemcpyAsync(d_ph, phases, count * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, D, d_ph, K->p.input_sigma, seed, d_ct);
+  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, K->p.input_dim > 0 ? K->p.input_dim : D, d_ph, K->p.input_sigma, seed, d_ct);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(cts, d_ct, count * (size_t)(D + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -22,7 +22,7 @@ class Tier(C.Structure):
 
 
 class Params(C.Structure):
-    _fields_ = [("D", C.c_int32), ("n_max", C.c_int32), ("n_tiers", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("D", C.c_int32), ("n_max", C.c_int32), ("n_tiers", C.c_int32), ("input_dim", C.c_int32),
                 ("input_sigma", C.c_double), ("tiers", Tier * MAX_TIERS)]
 
 

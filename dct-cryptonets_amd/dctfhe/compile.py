@@ -422,7 +422,7 @@ def _assign_encodings(circ):
         for s in ([o.src0, o.src1] if o.type == OP_ADD else [o.src0]):
             req[s] = need if req[s] is None else min(req[s], need)
     T[circ.input_tensor].e = req[circ.input_tensor]
-    T[circ.input_tensor].deff = circ.param_set.D
+    T[circ.input_tensor].deff = circ.param_set.input_dim or circ.param_set.D
     # a table whose output is only ever added (or decrypted) tolerates a noisier, cheaper tier
     amplified = [False] * len(T)
     for o in ops:

@@ -7,10 +7,10 @@ from . import _lib
 from ._lib import Params, Stats, Tier, Timing, check, ptr
 
 
-def make_params(D, n_max, tiers, input_sigma):
+def make_params(D, n_max, tiers, input_sigma, input_dim=0):
     """tiers: list of dicts with n,k,logN,l,beta,lk,betak,lwe_sigma,glwe_sigma[,ksk_share][,unroll]."""
     p = Params()
-    p.D, p.n_max, p.n_tiers, p.input_sigma = D, n_max, len(tiers), input_sigma
+    p.D, p.n_max, p.n_tiers, p.input_sigma, p.input_dim = D, n_max, len(tiers), input_sigma, input_dim
     for i, t in enumerate(tiers):
         p.tiers[i] = Tier(t["n"], t["k"], t["logN"], t["l"], t["beta"], t["lk"], t["betak"], t.get("ksk_share", -1),
                           t.get("unroll", 1), 0, t["lwe_sigma"], t["glwe_sigma"])

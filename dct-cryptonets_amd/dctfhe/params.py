@@ -61,11 +61,12 @@ class ParamSet:
     refresh_min_w: int = None          # tables this wide that feed a convolution are split: coarse look-up + small-ring refresh
     p_budget: float = 1e-12            # failure probability a single look-up site may spend on cheaper rounding steps
     input_sigma: float = 0.0
+    input_dim: int = 0                 # fresh encryptions mask only this prefix of the big key (0 = D); sets input_sigma's dimension
     fft_noise_c: float = 2.0           # empirical constant of the f64-FFT error term (tests/test_gpu_noise.py)
 
     def __post_init__(self):
         if self.input_sigma == 0.0:
-            self.input_sigma = sigma_min(self.D)
+            self.input_sigma = sigma_min(self.input_dim or self.D)
 
     @property
     def n_max(self):
@@ -115,7 +116,12 @@ def p_fail(margin, var):
 
 # ------------------------------------------------------------------------------------------ catalogue
 def default_params():
-    """Exact-evaluation set: every table site fails with probability <~1e-10 under the model above.
+    """Exact-evaluation set: every table site fails with probability < 1e-12 under the model above.
+
+    Small-key lengths: n = 832 for the table tiers and n = 584 for the one-bit tiers are the smallest (in steps of 8) that
+    keep every site of the four benchmark circuits under that budget once the key switch sums only over the effective
+    dimension of its input (2048 for everything downstream of a refresh or of the client, who encrypts under the first
+    2048 key bits: input_dim); the blind rotation is linear in n.
 
     T6 (6-bit tables after a rounded accumulator) needs N = 8192: its mod-switch noise must stay 6.4
     sigma inside a 2^-8 half-box.  T5/T4 serve the 5-bit residual-sum tables and the 4-bit rescale
@@ -123,24 +129,24 @@ def default_params():
     must stay near 2^-23: the f64 FFT error (~ N^2 B^2) forces small digits, hence three levels.
     B is the one-bit tier of the rounding chain: margin 1/4, so a small ring, but two levels because its
     output is subtracted from a p-bit accumulator."""
-    t6 = TierSpec("T6", n=864, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
-    t5 = TierSpec("T5", n=864, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
-    t4 = TierSpec("T4", n=864, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0, unroll=2)
-    b = TierSpec("B", n=660, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
+    t6 = TierSpec("T6", n=832, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
+    t5 = TierSpec("T5", n=832, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
+    t4 = TierSpec("T4", n=832, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0, unroll=2)
+    b = TierSpec("B", n=584, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
-    t6a = TierSpec("T6a", n=864, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
+    t6a = TierSpec("T6a", n=832, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     # Ba: one-level bit tier.  The output of rounding step i is amplified by 2^(p-j) only in the later steps j > i,
     # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
     # site, the first step from which Ba is safe.
-    ba = TierSpec("Ba", n=660, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
+    ba = TierSpec("Ba", n=584, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
-    t4r = TierSpec("T4r", n=864, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
+    t4r = TierSpec("T4r", n=832, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
     # T5a: one-level twin of T5; the 5-bit residual-sum table is split the same way (T5a + T4r ~0.9x of T5)
-    t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
+    t5a = TierSpec("T5a", n=832, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5)
+                    coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5, input_dim=2048)
 
 
 def params_for_p_error(p_error=0.01):
@@ -158,7 +164,7 @@ def params_for_p_error(p_error=0.01):
     t5a = TierSpec("T5a", n=864, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     ba = TierSpec("Ba", n=660, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
     return ParamSet(D=8192, tiers=[f6, f5, t4, b, t5a, ba], bit_tier=3, table_tier_for_w={4: 1, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 2, 6: 4}, bit_tier_coarse=5, p_budget=p_error / 4.0)
+                    coarse_tier_for_w={4: 2, 5: 2, 6: 4}, bit_tier_coarse=5, p_budget=p_error / 4.0, input_dim=2048)
 
 
 def test_params():
@@ -170,4 +176,4 @@ def test_params():
 
 def to_c_params(ps):
     from .engine import make_params
-    return make_params(ps.D, ps.n_max, [t.as_dict() for t in ps.tiers], ps.input_sigma)
+    return make_params(ps.D, ps.n_max, [t.as_dict() for t in ps.tiers], ps.input_sigma, ps.input_dim)

@@ -52,8 +52,9 @@ typedef struct {
   int32_t D;            /* big LWE dimension = length of the master binary key */
   int32_t n_max;        /* length of the small binary key */
   int32_t n_tiers;
-  int32_t reserved;
-  double input_sigma;   /* noise std of fresh client encryptions (under the big key) */
+  int32_t input_dim;    /* fresh client encryptions mask only the first input_dim words (a prefix of the big key, like
+                           every bootstrap output of a smaller ring); 0 = D.  input_sigma must suit that dimension. */
+  double input_sigma;   /* noise std of fresh client encryptions */
   dctfhe_tier tiers[DCTFHE_MAX_TIERS];
 } dctfhe_params;
 
