@@ -20,6 +20,7 @@ namespace dctfhe {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DCTFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define DCTFHE_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))   // the value is the same in every lane of the wave
+#define DCTFHE_DEVICE 1
 #else
 #define DCTFHE_SCHED_BARRIER() ((void)0)
 #define DCTFHE_UNIFORM(x) (x)
@@ -149,6 +150,31 @@ HD cplx root8(uint32_t k) { return cmk(dctfhe_cos8[k & 7], dctfhe_cos8[(k + 6) &
 HD cplx root8(uint32_t k) { return root64(8 * (int)(k & 7)); }
 #endif
 
+// Load base[lane] where `base` is the same in every lane: on the device the base goes through readfirstlane into scalar
+// registers and the load takes the scalar-base + 32-bit lane-offset form -- no 64-bit VALU address arithmetic (and no
+// carry-hazard nop) per load.  Global address space is stated explicitly so that it does not degrade to a flat load.
+// the same pointer, known to the compiler to be wave-uniform (two readfirstlanes once, free afterwards)
+HD const cplx* make_uniform(const cplx* p) {
+#if defined(DCTFHE_DEVICE)
+  const uint64_t v = (uint64_t)p;
+  return reinterpret_cast<const cplx*>(((uint64_t)DCTFHE_UNIFORM((uint32_t)(v >> 32)) << 32) | DCTFHE_UNIFORM((uint32_t)v));
+#else
+  return p;
+#endif
+}
+HD cplx load_uniform_base(const cplx* base, unsigned lane) {
+#if defined(DCTFHE_DEVICE)
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const uint64_t v = (uint64_t)base;
+  const uint32_t lo = DCTFHE_UNIFORM((uint32_t)v), hi = DCTFHE_UNIFORM((uint32_t)(v >> 32));
+  const __attribute__((address_space(1))) v2d* g = (const __attribute__((address_space(1))) v2d*)(((uint64_t)hi << 32) | lo);
+  const v2d x = g[lane];
+  return cmk(x.x, x.y);
+#else
+  return base[lane];
+#endif
+}
+
 struct pbs_args {
   const uint64_t* ct_small;   // this ciphertext: n+1 words
   int n;
@@ -229,7 +255,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 
   for (int i = 0; i < n; i += (MB ? 2 : 1)) {
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
-    const cplx* bsk_i = A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT;
+    const cplx* bsk_i = make_uniform(A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT);
     cplx out[K + 1][P];
     if constexpr (MB && !G::PAIR) {
       // general (k, l): one polynomial at a time through the single exchange buffer; the monomial factors are rebuilt per
@@ -286,7 +312,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #if defined(DCTFHE_ABLATE_BSK)
                 kk[w][q] = cmk(1.0 + w, 0.5 * q + row);
 #else
-                kk[w][q] = key[((size_t)w * G::ROWS * (K + 1) + (size_t)row * (K + 1) + q) * M + j * T + t];
+                kk[w][q] = load_uniform_base(key + (((size_t)w * G::ROWS * (K + 1) + (size_t)row * (K + 1) + q) * M + j * T), (unsigned)t);    // uniform base + lane index
 #endif
               });
             });
@@ -344,7 +370,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #if defined(DCTFHE_ABLATE_BSK)
               kk[w][r] = cmk(1.0 + w, 0.5 * q + r);
 #else
-              kk[w][r] = key[(size_t)((w * 2 + r) * 2 + q) * M + j * T + t];
+              kk[w][r] = load_uniform_base(key + ((size_t)((w * 2 + r) * 2 + q) * M + j * T), (unsigned)t);      // uniform base + zero-extended lane index: scalar address math
 #endif
             });
           });
@@ -394,8 +420,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #if defined(DCTFHE_ABLATE_BSK)
             k0[j] = cmk(1.0 + j, 0.5 * q); k1[j] = cmk(0.5 * q, 1.0 + j);
 #else
-            k0[j] = bsk_i[(size_t)(0 * 2 + q) * M + (j0 + j) * T + t];
-            k1[j] = bsk_i[(size_t)(1 * 2 + q) * M + (j0 + j) * T + t];
+            k0[j] = load_uniform_base(bsk_i + ((size_t)(0 * 2 + q) * M + (j0 + j) * T), (unsigned)t);
+            k1[j] = load_uniform_base(bsk_i + ((size_t)(1 * 2 + q) * M + (j0 + j) * T), (unsigned)t);
 #endif
           });
           DCTFHE_SCHED_BARRIER();
@@ -467,7 +493,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #if defined(DCTFHE_ABLATE_BSK)   // timing experiments only (tools/exp_pbs.hip): no key traffic
               kb[j] = cmk(1.0 + j, 0.5 * q);
 #else
-              kb[j] = row[(size_t)q * M + (j0 + j) * T + t];
+              kb[j] = load_uniform_base(row + ((size_t)q * M + (j0 + j) * T), (unsigned)t);
 #endif
             });
             DCTFHE_SCHED_BARRIER();
