@@ -482,7 +482,10 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
         // (at this register pressure) emits load; s_waitcnt vmcnt(0); fma -- 16 serialized L2 round trips per row
         // (measured 93 -> 72 ms per launch).  Issuing the first batch under the last FFT pass was tried and lost
         // (more scratch traffic than latency hidden).
-        constexpr int KB = (P > PBS_KEY_BATCH) ? PBS_KEY_BATCH : P;      // key loads in flight per thread and batch
+        // key loads in flight per thread and batch: 4 everywhere but on the one-level k = 2 kernel, whose 32-bit accumulators
+        // leave room for 8 (41.3 -> 37.4 ms per launch; 8 still spills on the two-level k = 2 kernel: 92 -> 101 ms)
+        constexpr int KBW = (K >= 2 && L == 1 && G::ACC32) ? 8 : PBS_KEY_BATCH;
+        constexpr int KB = (P > KBW) ? KBW : P;
         static_for<0, K + 1>([&](auto Q) {
           constexpr int q = decltype(Q)::value;
           static_for<0, P / KB>([&](auto Hb) {
