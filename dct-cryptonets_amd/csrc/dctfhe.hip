@@ -561,8 +561,15 @@ static void free_lut_scratch(LutScratch* sc) {
 }
 
 // ------------------------------------------------------------------------------------------ primitives on host buffers
+extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, int deff,
+                                       uint64_t* cts_small);
 extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, uint64_t* cts_small) {
+  return dctfhe_keyswitch_prefix(ctx, K, tier, cts, count, shift, 0, cts_small);
+}
+extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, int deff,
+                                       uint64_t* cts_small) {
   if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  if (deff < 0 || deff > K->p.D) return fail("deff out of range");
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
   const dctfhe_tier& t = K->p.tiers[tier];
@@ -573,7 +580,7 @@ extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const
   HIPCHK(hipMalloc(&d_bodies, count * 8));
   HIPCHK(hipMalloc(&d_dig, count * (size_t)K->p.D * t.lk));
   HIPCHK(hipMemcpy(d_in, cts, count * L * 8, hipMemcpyHostToDevice));
-  CHK(dev_keyswitch(K, tier, d_in, count, shift, d_dig, d_bodies, d_small, nullptr));
+  CHK(dev_keyswitch(K, tier, d_in, count, shift, d_dig, d_bodies, d_small, nullptr, deff));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cts_small, d_small, count * (size_t)(t.n + 1) * 8, hipMemcpyDeviceToHost));
   hipFree(d_in); hipFree(d_small); hipFree(d_bodies); hipFree(d_dig);

@@ -93,10 +93,11 @@ class Keys:
         check(self.L.dctfhe_decrypt(self.ctx.h, self.h, ptr(cts), cts.shape[0], ptr(out)))
         return out
 
-    def keyswitch(self, tier, cts, shift=0):
+    def keyswitch(self, tier, cts, shift=0, deff=0):
+        """deff > 0: the caller knows every mask word beyond deff to be zero (see dctfhe_keyswitch_prefix)"""
         cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, self.D + 1)
         out = np.empty((cts.shape[0], self.tier(tier).n + 1), np.uint64)
-        check(self.L.dctfhe_keyswitch(self.ctx.h, self.h, tier, ptr(cts), cts.shape[0], shift, ptr(out)))
+        check(self.L.dctfhe_keyswitch_prefix(self.ctx.h, self.h, tier, ptr(cts), cts.shape[0], shift, deff, ptr(out)))
         return out
 
     def pbs(self, tier, cts_small, tables, w, table_idx=None):

@@ -106,6 +106,10 @@ int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_keys* keys, const uint64_t* cts, size
 /* R4, server half, one primitive at a time on host buffers (parity tests, integration). */
 int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts, size_t count,
                      int shift, uint64_t* cts_small /* count x (n+1) */);
+/* the same when the caller knows every input to be zero beyond mask word `deff` (nested keys: outputs of a ring of
+ * dimension k*N <= deff): only the first deff rows of the key are used -- identical result, deff/D of the work */
+int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts, size_t count,
+                            int shift, int deff, uint64_t* cts_small);
 int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts_small, size_t count,
                const int64_t* tables /* [ntab][2^w] */, int ntab, int w, const int32_t* table_idx /* may be NULL */,
                uint64_t* cts_out /* count x (D+1) */);

@@ -58,6 +58,20 @@ def test_keyswitch_bit_exact(keys, oracle):
         assert np.abs(_centered(ph - phases)).max() < 2.0 ** -6
 
 
+def test_keyswitch_on_effective_dimension(keys, oracle):
+    """Ciphertexts with a zero tail (nested keys: outputs of a smaller ring): switching over the first deff key rows only
+    gives the full key switch bit for bit -- device against itself and against the oracle."""
+    rng = np.random.default_rng(4)
+    for tier, deff in ((0, 512), (1, 256), (0, 1024)):
+        t = TIERS_SMALL[tier]
+        cts = rng.integers(0, 2 ** 64, (37, D_SMALL + 1), dtype=np.uint64)
+        cts[:, deff:D_SMALL] = 0
+        full = keys.keyswitch(tier, cts, shift=2)
+        pref = keys.keyswitch(tier, cts, shift=2, deff=deff)
+        assert np.array_equal(full, pref), (tier, deff)
+        assert np.array_equal(pref, oracle.keyswitch(cts << np.uint64(2), keys.export_ksk(tier), t["betak"]))
+
+
 @pytest.mark.parametrize("tier,w", [(0, 4), (1, 3), (2, 4)])
 def test_pbs_all_messages(keys, oracle, tier, w):
     """decrypt(PBS_f(enc(m))) == f(m) for every m; device and oracle agree on decrypted values."""
