@@ -137,6 +137,11 @@ class CompiledCircuit:
         t = self.tensors[self.output_tensor]
         return t.C * t.H * t.W
 
+    @property
+    def worst_site_failure(self):
+        """largest modelled failure probability per element over the look-up sites"""
+        return max((o.pfail for o in self.ops if o.type == OP_LUT), default=0.0)
+
     def pbs_counts(self):
         """{tier name: programmable bootstraps per image} -- table lookups on the site's table tier, rounding steps
         on the bit tier (steps below coarse_from) or the one-level bit tier (steps from coarse_from on)."""
@@ -263,7 +268,7 @@ class _Builder:
         identity 'refresh' bootstrap on a small ring (ParamSet.refresh_min_w)"""
         y = self.lut(a, fn, per_channel, rounding, out_scale, note)
         op = self.ops[-1]
-        if self.ps.refresh_min_w is not None and op.w >= self.ps.refresh_min_w and y.lo >= 0:
+        if self.ps.refresh_min_w is not None and op.w >= self.ps.refresh_min_w:
             y = self.lut(y, lambda vals: vals, False, False, out_scale, note + " (refresh)")
         return y
 
@@ -309,6 +314,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
         raise ValueError(f"rounding_method {rounding_method!r}")
     if tier_policy not in ("exact", "p_error"):
         raise ValueError(f"tier_policy {tier_policy!r}")
+    own_catalogue = param_set is None
     if param_set is None:
         param_set = P.params_for_p_error(p_error if p_error is not None else 0.01) if tier_policy == "p_error" else P.default_params()
     ps = param_set
@@ -405,6 +411,10 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
                            rounding_threshold_bits=rounding_threshold_bits, n_bits=n_bits, rounding_method=rounding_method)
     _assign_encodings(circ)
     _estimate_noise(circ)
+    if own_catalogue and tier_policy == "exact" and circ.worst_site_failure > 1e-10:
+        import warnings
+        warnings.warn(f"dctfhe: a look-up site exceeds the exact-evaluation budget (p_fail/element {circ.worst_site_failure:.1e}); "
+                      "outputs may differ from the integer circuit -- see CompiledCircuit.report()")
     circ.blob = _serialize(circ)
     return circ
 

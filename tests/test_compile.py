@@ -90,3 +90,23 @@ def test_approximate_rounding_and_p_error_policy(tiny):
     assert max(o.pfail for o in fast.ops if o.type == cc.OP_LUT) <= 0.01
     with pytest.raises(ValueError):
         cc.compile_model(models.tiny_resnet_q(), calib, p_error=0.5, tier_policy="p_error")
+
+
+@pytest.mark.parametrize("name,in_ch,img,front", [("ResNet20QAT", 24, 16, "dct4"), ("ResNet20QAT", 3, 32, "rgb"), ("ResNet18QAT", 3, 32, "rgb"),
+                                                  ("ResNet18QAT", 48, 112, "dct8")])
+def test_exact_catalogue_keeps_every_site_in_budget(name, in_ch, img, front):
+    """the default catalogue (n = 832 / 584, effective-dimension key switch) keeps every look-up site of the benchmark
+    topologies under 1e-12 per element -- including ResNet-18's signed stem output, which is refreshed like the others
+    (config #5 with four calibration images to keep the test short)"""
+    from dctfhe import compile as cc, frontend, models, synthetic
+    if front == "dct4":
+        tf = frontend.dct_eval_transform(filter_size=4, image_size_dct=img, channels=in_ch)
+    elif front == "dct8":
+        tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=img, channels=in_ch)
+    else:
+        tf = frontend.rgb_eval_transform(img)
+    x = np.stack([tf(im) for im in synthetic.synthetic_images(24 if img <= 32 else 4, 7, size=64)]).astype(np.float32)
+    model = getattr(models, name)(bit_width=4, in_channels=in_ch, img_size=img, seed=0)
+    c = cc.compile_model(model, x, rounding_threshold_bits=6, n_bits=5)
+    assert c.worst_site_failure <= 1e-12, c.worst_site_failure
+    assert "T6" not in c.pbs_counts() and "T5" not in c.pbs_counts()        # every wide conv-feeding table is split
