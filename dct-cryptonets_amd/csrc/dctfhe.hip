@@ -105,6 +105,9 @@ struct dctfhe_session {
   uint64_t* d_small = nullptr;
   int64_t* d_bit_tables = nullptr;  // 64 single-entry tables: 2^j
   int* d_overflow = nullptr;
+  // `simulate`: per-op noise (fraction of the torus) injected by the clear look-up kernel; empty = noise-free
+  std::vector<double> sim_sigma;
+  uint64_t sim_seed = 0, sim_run = 0;
 };
 
 // ------------------------------------------------------------------------------------------ kernel dispatch
@@ -856,6 +859,14 @@ extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) 
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   return 0;
 }
+extern "C" int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const double* sigma_per_op, int n_ops) {
+  if (s->keys) return fail("noise simulation is a clear-mode feature: create the session without keys");
+  if (n_ops != 0 && n_ops != (int)s->circ->ops.size()) return fail("expected one sigma per op (%zu), got %d", s->circ->ops.size(), n_ops);
+  s->sim_sigma.assign(sigma_per_op, sigma_per_op + n_ops);
+  s->sim_seed = seed;
+  return 0;
+}
+
 extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->output_tensor;
@@ -912,8 +923,9 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
         const uint64_t body_add = (uint64_t)o.lp[0];
         const int hw = a.H * a.W;
         if (!K) {
+          const double sg = i < s->sim_sigma.size() ? s->sim_sigma[i] : 0.0;
           hipLaunchKernelGGL(k_lut_clear, dim3(ew_grid(E)), dim3(256), 0, st, src, dst, E, shift, body_add, p, r, w, (const int64_t*)c->d_payload[i],
-                             hw, nchan, s->d_overflow);
+                             hw, nchan, s->d_overflow, sg, s->sim_seed, (uint64_t)(0x51D0000 + (s->sim_run << 12) + i), (int)(o.ip[9] != 0));
           HIPCHK(hipGetLastError());
         } else {
           const int h = tm.begin(CAT_LINEAR);
@@ -933,6 +945,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
       default: return fail("op %zu: unknown type %d", i, o.type);
     }
   }
+  s->sim_run++;
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipEventSynchronize(e1));
   if (timing) {

@@ -488,14 +488,32 @@ __global__ void k_sum_pool(const uint64_t* __restrict__ in, int C, int H, int W,
   }
 }
 
-// clear-mode table look-up on 1-word "ciphertexts" (D = 0): same arithmetic as round_lut without noise
+// clear-mode table look-up on 1-word "ciphertexts" (D = 0): same arithmetic as round_lut without noise.
+// sigma > 0 (`simulate` with the noise model): Gaussian noise of that standard deviation (fraction of the torus: what the
+// compiler predicts at the input of this site's table bootstrap) is added where the encrypted run has it -- after the exact
+// rounding steps have cleared the low bits, or, with approximate rounding, on the raw accumulator -- and the half-box
+// rotation of the test vector does the rest.
 __global__ void k_lut_clear(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t count, int shift, uint64_t body_add,
-                            int p, int r, int w, const int64_t* __restrict__ tables, int hw, int nchan, int* __restrict__ overflow) {
+                            int p, int r, int w, const int64_t* __restrict__ tables, int hw, int nchan, int* __restrict__ overflow,
+                            double sigma, uint64_t seed, uint64_t stream, int approx) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
     uint64_t v = (in[e] << shift) + body_add;
-    if (r > 0) v += 1ULL << (63 - p + r - 1);
+    if (r > 0 && !(approx && sigma > 0)) v += 1ULL << (63 - p + r - 1);
     if (v >> 63) atomicOr(overflow, 1);  // message left the padded range: an FHE run would wrap
-    const uint64_t idx = (v >> (63 - w)) & ((1ULL << w) - 1);
+    uint64_t idx = (v >> (63 - w)) & ((1ULL << w) - 1);
+    if (sigma > 0) {
+      const uint64_t half_box = 1ULL << (62 - w);
+      // exact rounding: the value sits at the centre of its box; approximate: where its low bits put it (+ half an input unit)
+      const uint64_t centre = approx && r > 0 ? v + (1ULL << (62 - p)) : (idx << (63 - w));
+      const uint64_t noisy = centre + (uint64_t)gauss_torus(seed, stream, e, sigma);
+      // negacyclic wrap: a value pushed across the padding bit comes back negated -- reproduce the bootstrap's behaviour
+      const uint64_t pos = noisy + half_box;
+      idx = (pos >> (63 - w)) & ((1ULL << w) - 1);
+      const size_t ti = nchan > 1 ? (e / (size_t)hw) % (size_t)nchan : 0;
+      const uint64_t t = (uint64_t)tables[(ti << w) + idx];
+      out[e] = (pos >> 63) ? (uint64_t)0 - t : t;
+      continue;
+    }
     const size_t ti = nchan > 1 ? (e / (size_t)hw) % (size_t)nchan : 0;
     out[e] = (uint64_t)tables[(ti << w) + idx];
   }

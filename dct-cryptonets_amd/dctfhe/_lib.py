@@ -41,7 +41,7 @@ class Timing(C.Structure):
 EXPORTS = [
     "dctfhe_last_error", "dctfhe_version", "dctfhe_ctx_create", "dctfhe_ctx_destroy", "dctfhe_ctx_set_stream",
     "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_keys_destroy", "dctfhe_keys_export_secret",
-    "dctfhe_keys_export_ksk", "dctfhe_keys_export_bsk", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix",
+    "dctfhe_keys_export_ksk", "dctfhe_keys_export_bsk", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
     "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_circuit_load", "dctfhe_circuit_destroy",
     "dctfhe_circuit_stats", "dctfhe_circuit_io", "dctfhe_session_create", "dctfhe_session_destroy",
     "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
@@ -77,6 +77,7 @@ def load():
     L.dctfhe_encrypt.argtypes = [vp, vp, vp, sz, u64, vp]
     L.dctfhe_decrypt.argtypes = [vp, vp, vp, sz, vp]
     L.dctfhe_keyswitch.argtypes = [vp, vp, i32, vp, sz, i32, vp]
+    L.dctfhe_session_set_noise.argtypes = [vp, C.c_uint64, vp, i32]
     L.dctfhe_keyswitch_prefix.argtypes = [vp, vp, i32, vp, sz, i32, i32, vp]
     L.dctfhe_pbs.argtypes = [vp, vp, i32, vp, sz, vp, i32, i32, vp, vp]
     L.dctfhe_round_lut.argtypes = [vp, vp, i32, i32, vp, sz, i32, i32, vp, i32, i32, vp, vp]

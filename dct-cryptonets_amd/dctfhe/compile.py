@@ -100,6 +100,7 @@ class OpInfo:
     note: str = ""
     pfail: float = 0.0
     coarse_from: int = -1             # rounding steps i >= coarse_from run on the one-level bit tier
+    sim_sigma: float = 0.0            # modelled noise std at the input of the site's table bootstrap (fraction of the torus)
 
 
 @dataclass
@@ -141,6 +142,10 @@ class CompiledCircuit:
     def worst_site_failure(self):
         """largest modelled failure probability per element over the look-up sites"""
         return max((o.pfail for o in self.ops if o.type == OP_LUT), default=0.0)
+
+    def simulation_sigmas(self):
+        """per op, the noise std `simulate` injects at the look-up (0 for the levelled ops)"""
+        return [o.sim_sigma if o.type == OP_LUT else 0.0 for o in self.ops]
 
     def pbs_counts(self):
         """{tier name: programmable bootstraps per image} -- table lookups on the site's table tier, rounding steps
@@ -514,6 +519,12 @@ def _estimate_noise(circ):
                 o.coarse_from = o.ip[8] = cf
                 pf = site_pfail(cf)
             o.pfail = pf
+            v_sim = v_in0
+            if o.r > 0 and not approx:                      # what the rounding steps leave on the working ciphertext
+                bt = ps.tiers[o.ip[5]]
+                for i in range(o.r):
+                    v_sim += P.var_pbs_out(ps.tiers[o.ip[7]] if (i >= o.ip[8] and o.ip[7] >= 0) else bt, ps.fft_noise_c)
+            o.sim_sigma = math.sqrt(v_sim + v_tab_in)
             if approx:
                 flips += (2.0 / 2 ** o.r) * P.p_fail(2.0 ** -(o.p + 2), v_in0 + v_tab_in) * n_elt
             total += pf * n_elt

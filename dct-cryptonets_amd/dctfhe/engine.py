@@ -164,6 +164,14 @@ class Session:
         assert cts.size == self.batch * self.circuit.n_in * self.words, (cts.shape, self.batch, self.circuit.n_in, self.words)
         check(self.L.dctfhe_session_upload(self.h, ptr(cts)))
 
+    def set_noise(self, seed, sigma_per_op):
+        """clear-mode sessions: `simulate` with the noise model (sigma per op, fraction of the torus); None switches it off"""
+        if sigma_per_op is None:
+            check(self.L.dctfhe_session_set_noise(self.h, 0, None, 0))
+            return
+        sg = np.ascontiguousarray(sigma_per_op, np.float64)
+        check(self.L.dctfhe_session_set_noise(self.h, seed, ptr(sg), sg.size))
+
     def run(self, timing=False):
         t = Timing() if timing else None
         check(self.L.dctfhe_session_run(self.h, C.byref(t) if timing else None))

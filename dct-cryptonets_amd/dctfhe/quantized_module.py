@@ -66,6 +66,7 @@ class QuantizedModule:
         self._sessions = {}
         self.fhe_circuit = FHECircuit(self)
         self.last_timing = None
+        self.sim_seed = 977
         self.enc_seed = 1000
 
     # -- lazy device objects -------------------------------------------------------------
@@ -129,6 +130,14 @@ class QuantizedModule:
         B = q.shape[0]
         mode = "execute" if fhe == "execute" else "clear"
         sess = self._session(mode, B)
+        if mode == "clear":
+            # "simulate" = the integer circuit with the compiler's noise model sampled at every look-up (reference: Concrete's
+            # simulation, homomorphic_eval.py:333-347); "disable" = noise-free.  At the exact tiers the two coincide.
+            if fhe == "simulate":
+                sess.set_noise(self.sim_seed, self.compiled.simulation_sigmas())
+                self.sim_seed += 1
+            else:
+                sess.set_noise(0, None)
         t0 = time.time()
         if mode == "execute":
             cts = self._keys.encrypt(phases.reshape(-1), self.enc_seed)

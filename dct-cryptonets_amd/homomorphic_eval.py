@@ -151,9 +151,9 @@ def main():
     print(f"[Test] Top-1 Acc: {top1.avg:.3f}% | Top-5 Acc: {top5.avg:.3f}% | Time per inference in FHE: {time_per_inference:.2f}")
 
     # reliability analysis over random subsets (reference homomorphic_eval.py:366-440: random states 27 and 28, simulate only).
-    # `simulate` here evaluates the integer circuit in the clear: the engine's parameter tiers are the exact-evaluation set
-    # (expected failing look-ups per image ~2e-7, printed by the compiler), so sampling the noise model cannot be told from
-    # the clear circuit; the reference's p_error = 0.01 stochasticity is deliberately not reproduced.
+    # `simulate` samples the compiler's noise model at every look-up; with the default exact-evaluation tiers (expected
+    # failing look-ups per image ~1e-7) that coincides with the clear circuit, with --tier_policy p_error / --rounding_method
+    # approximate it reproduces the reference-style stochastic regime.
     if params.reliability_test is not None and params.fhe_mode == "simulate":
         print("\n============ Encrypted Reliability Analysis ============")
         top1_plain, top5_plain, top1_enc, top5_enc = [], [], [], []

@@ -132,6 +132,9 @@ int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_keys* ke
 int dctfhe_session_destroy(dctfhe_session* s);
 int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in /* batch x n_in x (D+1); clear: x 1 */);
 int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing /* may be NULL */);
+/* clear-mode sessions (keys == NULL) only: `simulate` with the noise model.  sigma_per_op[i] (fraction of the torus, 0 for
+ * ops that are not look-ups) is added at the input of op i's table look-up, fresh draws every run; n_ops = 0 switches it off */
+int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const double* sigma_per_op, int n_ops);
 int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out /* batch x n_out x (D+1) */);
 
 /* f64 FMA peak micro-benchmark (TFLOP/s) used to price the blind-rotate kernel in bench.py. */

@@ -119,3 +119,31 @@ def test_p_error_tier_policy_full_size_rings():
         assert (diff == 0).mean() > 0.5 and diff.max() <= 4
     finally:
         qm.close()
+
+
+def test_simulate_samples_the_noise_model():
+    """fhe="simulate" = the integer circuit with the compiler's noise model sampled at every look-up: at the
+    exact tiers it coincides with the clear circuit; with approximate rounding and the p_error tiers it shows the same kind
+    of deviation as the encrypted run (boundary flips), and two simulations draw different noise."""
+    from dctfhe import models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    exact = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits=6)      # default (exact) catalogue
+    try:
+        q = exact.quantize_input(calib[:8])
+        assert np.array_equal(exact.forward_quantized(q, "simulate"), exact.forward_quantized(q, "disable"))
+    finally:
+        exact.close()
+    fast = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits={"n_bits": 6, "method": "approximate"},
+                                      p_error=0.01, tier_policy="p_error")
+    try:
+        q = fast.quantize_input(calib[:8])
+        clear = fast.forward_quantized(q, "disable")
+        s1, s2 = fast.forward_quantized(q, "simulate"), fast.forward_quantized(q, "simulate")
+        d1 = np.abs(s1 - clear)
+        assert 0 < (d1 != 0).mean() < 0.6 and d1.max() <= 4          # deviates, mildly
+        assert not np.array_equal(s1, s2)                           # fresh draws every run
+        assert np.array_equal(fast.forward_quantized(q, "disable"), clear)
+    finally:
+        fast.close()
