@@ -4,4 +4,4 @@ set -e
 cd "$(dirname "$0")/.."
 OUT=${2:-exp_pbs}
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -Wno-unused-value $3 -DEXP_CASES="$1" -o tools/$OUT tools/exp_pbs.hip -Rpass-analysis=kernel-resource-usage 2> /tmp/exp_build.log || { grep error /tmp/exp_build.log | head; exit 1; }
-python /tmp/res.py /tmp/exp_build.log | grep pbs_kernel
+python "$(dirname "$0")/resource_usage.py" /tmp/exp_build.log | grep pbs_kernel
