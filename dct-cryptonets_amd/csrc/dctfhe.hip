@@ -856,6 +856,24 @@ extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) 
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->input_tensor;
   HIPCHK(hipMemcpyAsync(s->d_tensor[t], cts_in, s->tensor_words[t] * 8, hipMemcpyHostToDevice, s->ctx->stream));
+  // the circuit was compiled for inputs that are zero beyond their effective dimension (client encryption on a key prefix,
+  // dctfhe_params.input_dim): the key switch and the convolutions skip that tail, so make sure it really is empty
+  if (s->keys) {
+    int deff = 0;
+    for (const Op& o : s->circ->ops)
+      if (o.src0 == t) { deff = o.ip[10]; break; }
+    if (deff > 0 && deff < s->D) {
+      const size_t count = s->tensor_words[t] / (size_t)(s->D + 1);
+      HIPCHK(hipMemsetAsync(s->d_overflow, 0, sizeof(int), s->ctx->stream));
+      hipLaunchKernelGGL(k_tail_nonzero, dim3(ew_grid(count * (size_t)(s->D - deff))), dim3(256), 0, s->ctx->stream, s->d_tensor[t], count, s->D, deff,
+                         s->d_overflow);
+      HIPCHK(hipGetLastError());
+      int bad = 0;
+      HIPCHK(hipMemcpyAsync(&bad, s->d_overflow, sizeof bad, hipMemcpyDeviceToHost, s->ctx->stream));
+      HIPCHK(hipStreamSynchronize(s->ctx->stream));
+      if (bad) return fail("input ciphertexts have non-zero mask words beyond %d: encrypt them with these parameters (input_dim)", deff);
+    }
+  }
   HIPCHK(hipStreamSynchronize(s->ctx->stream));
   return 0;
 }

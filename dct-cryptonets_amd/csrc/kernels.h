@@ -460,6 +460,15 @@ k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1
   }
 }
 
+// any non-zero mask word in [deff, D) of `count` ciphertexts?  (guards the effective-dimension shortcut at the session input)
+__global__ void k_tail_nonzero(const uint64_t* __restrict__ cts, size_t count, int D, int deff, int* __restrict__ flag) {
+  const size_t tail = (size_t)(D - deff), total = count * tail;
+  int bad = 0;
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x)
+    bad |= cts[(x / tail) * (size_t)(D + 1) + deff + (x % tail)] != 0;
+  if (bad) atomicOr(flag, 1);
+}
+
 // ------------------------------------------------------------------------------------------ K2 elementwise
 __global__ void k_add(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ o, size_t nwords) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];

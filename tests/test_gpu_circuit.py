@@ -147,3 +147,29 @@ def test_simulate_samples_the_noise_model():
         assert np.array_equal(fast.forward_quantized(q, "disable"), clear)
     finally:
         fast.close()
+
+
+def test_input_on_a_key_prefix_and_tail_guard():
+    """dctfhe_params.input_dim: the client masks only a prefix of the big key, the compiler propagates the effective
+    dimension and the key switch / convolutions skip the zero tail -- same outputs as the integer circuit; ciphertexts that
+    are not zero beyond that prefix are refused at upload (they would be evaluated wrongly)."""
+    import dataclasses
+    from dctfhe import _lib, models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    ps = dataclasses.replace(P.test_params(), input_dim=512)
+    qm = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits=6, param_set=ps)
+    try:
+        assert qm.compiled.tensors[qm.compiled.input_tensor].deff == 512
+        qm.fhe_circuit.keygen(seed=11)
+        q = qm.quantize_input(calib[:3])
+        assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
+        cts = qm._keys.encrypt(qm.encode_input(q).reshape(-1), 77).reshape(-1, qm._keys.D + 1)
+        assert not cts[:, 512:qm._keys.D].any()
+        cts[5, 700] = 1
+        sess = qm._session("execute", 3)
+        with pytest.raises(_lib.DctfheError, match="beyond 512"):
+            sess.upload(cts)
+    finally:
+        qm.close()
