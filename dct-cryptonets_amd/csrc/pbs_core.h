@@ -40,6 +40,15 @@ namespace dctfhe {
 #ifndef PBS_PAIR
 #define PBS_PAIR 1
 #endif
+#ifndef PBS_MB_BAR_A
+#define PBS_MB_BAR_A() DCTFHE_SCHED_BARRIER()
+#endif
+#ifndef PBS_MB_BAR_B
+#define PBS_MB_BAR_B() ((void)0)     // no barrier after the fold: hipcc may hoist the next batch's loads over it (+3 %)
+#endif
+#ifndef PBS_STD_BAR_B
+#define PBS_STD_BAR_B() DCTFHE_SCHED_BARRIER()
+#endif
 
 // one-level tiers keep the accumulator as 32-bit torus values (see pbs_geom::ACC32)
 #ifndef PBS_ACC32
@@ -374,7 +383,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #endif
             });
           });
-          DCTFHE_SCHED_BARRIER();
+          PBS_MB_BAR_A();
           const cplx m1 = cmk(z1.re - 1.0, z1.im), m2 = cmk(z2.re - 1.0, z2.im);
           cplx m12 = cmul(z1, z2); m12.re -= 1.0;
           static_for<0, 2>([&](auto Rr) {
@@ -382,7 +391,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             const cplx bundle = cfma(m12, kk[2][r], cfma(m2, kk[1][r], cmul(m1, kk[0][r])));
             if constexpr (r == 0) out[q][j] = cmul(v[0][j], bundle); else out[q][j] = cfma(v[1][j], bundle, out[q][j]);
           });
-          DCTFHE_SCHED_BARRIER();
+          PBS_MB_BAR_B();
         });
       });
     } else if constexpr (G::PAIR) {
@@ -501,7 +510,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             });
             DCTFHE_SCHED_BARRIER();
             static_for<0, KB>([&](auto J) { constexpr int j = decltype(J)::value; out[q][j0 + j] = cfma(v[j0 + j], kb[j], out[q][j0 + j]); });
-            DCTFHE_SCHED_BARRIER();
+            PBS_STD_BAR_B();
           });
         });
       });
