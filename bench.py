@@ -4,28 +4,34 @@
 Metric (BASELINE.json): encrypted images/sec (+ s/image), ResNet-20 DCT 24x16^2 CIFAR-10 trunk.
 A "step" is one pass of the homomorphic circuit (dctfhe_session_run: every conv, add, exact rounding,
 key switch and bootstrap of the trunk) over one batch of synthetic encrypted images that is already
-resident in HBM.  The batch shards by image across ranks (one process per GPU); there is no collective
-on the data path -- the only exchange is one RCCL all_gather of the decrypted-side logits at the end.
+resident in HBM (reference timed loop: homomorphic_eval.py:350-361, `elapsed / test_subset`).  The batch
+shards by image across ranks (one process per GPU); there is no collective on the data path -- the only
+exchange is one RCCL all_gather of the decrypted-side logits at the end.
 
-Usage:  python bench.py --gpus N --steps K --warmup W [--batch-per-gpu B]
-        (N > 1: launched by torch.distributed.run, one rank per GPU)
+Usage:  python bench.py --gpus N --steps K --warmup W [--batch-per-gpu B] [--budget-s S]
+  * N > 1 without WORLD_SIZE in the environment: bench.py starts its own N ranks (child processes of
+    `python -m torch.distributed.run`, before anything here touches a GPU) and exits with their code;
+    under torch.distributed.run it is one of the ranks.
+  * One encrypted image takes seconds, so K and W are CAPPED by a wall-clock budget (--budget-s, default 450 s from
+    process start, env DCTFHE_BENCH_BUDGET_S): after the first pass the loop keeps as many of the requested passes
+    as fit; the JSON reports the steps / warm-up passes actually run (and `requested`).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import math
 import os
+import signal
+import subprocess
 import sys
+import threading
 import time
 
+T_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "dct-cryptonets_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not list it, so the live FMA probe is reported beside it)
@@ -37,6 +43,7 @@ def _dct_batch(n, seed):
 
 
 def _rgb_batch(n, seed):
+    import numpy as np
     from dctfhe import frontend, synthetic
     tf = frontend.rgb_eval_transform(32)
     return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed)]).astype(np.float32)
@@ -44,6 +51,7 @@ def _rgb_batch(n, seed):
 
 def _dct8_112_batch(n, seed):
     """config #5: 8x8 JPEG-domain DCT, 48 channels, 112x112: Resize(1030) -> CenterCrop(896) -> 8x8 DCT"""
+    import numpy as np
     from dctfhe import frontend, synthetic
     tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=112, channels=48)
     return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed, size=96)]).astype(np.float32)
@@ -51,7 +59,7 @@ def _dct8_112_batch(n, seed):
 
 # name -> (model factory name, in_channels, img_size, input batch maker, description)
 CONFIGS = {
-    "r20_24_16": ("ResNet20QAT", 24, 16, _dct_batch, "ResNet-20 24x16^2 DCT CIFAR-10 trunk (BASELINE config #2 shape)"),
+    "r20_24_16": ("ResNet20QAT", 24, 16, _dct_batch, "ResNet-20 24x16^2 DCT CIFAR-10 trunk (BASELINE config #1/#2 shape)"),
     "r20_3_32": ("ResNet20QAT", 3, 32, _rgb_batch, "ResNet-20 3x32^2 RGB CIFAR-10 trunk (BASELINE config #3)"),
     "r18_3_32": ("ResNet18QAT", 3, 32, _rgb_batch, "ResNet-18 3x32^2 RGB CIFAR-10 trunk (BASELINE config #4 shape)"),
     "r18_48_112": ("ResNet18QAT", 48, 112, _dct8_112_batch, "ResNet-18 48x112^2 DCT ImageNet trunk (BASELINE config #5 shape; 16 calibration images)"),
@@ -59,108 +67,179 @@ CONFIGS = {
 
 
 def measured_hbm_traffic(kernel_tag, cts_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/pmc_summary.py; FETCH_SIZE and
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/rocprof_db_summary.py; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected inside this run).  Scaled by ciphertexts per
     launch; None when the summary has no entry for this kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-    if not os.path.exists(path):
-        return None
-    prof = json.load(open(path))
-    for k, v in prof.items():
-        if kernel_tag in k.replace(" ", "") and v.get("launches"):
-            per_ct = v["hbm_bytes_per_launch"] / v.get("cts_per_launch", cts_per_launch)
-            return per_ct * cts_per_launch
+    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        prof = json.load(open(path))
+        for k, v in prof.items():
+            if kernel_tag in k.replace(" ", "") and v.get("launches"):
+                per_ct = v["hbm_bytes_per_launch"] / v.get("cts_per_launch", cts_per_launch)
+                return per_ct * cts_per_launch
     return None
 
 
-def cpu_baseline(qm, stats, n_prime=16):
-    """Times the CPU oracle (oracle/tfhe_ref.c, the C twin) on a bounded sample and extrapolates to images/s.
-    Sample: per tier, `threads` ciphertexts through n'=16 blind-rotate iterations and a key switch onto n'+1
-    columns -- both costs are exactly linear in n, so they are scaled by n/n' -- plus one 3x3 ciphertext conv."""
-    # the GPU box shares its host cores: keep to the one-GPU CPU share (16), and say how many were used
+def conv_macs_of(compiled):
+    macs = 0
+    for o in compiled.ops:
+        if o.type == 1:
+            s, d = compiled.tensors[o.src0], compiled.tensors[o.dst]
+            macs += d.C * d.H * d.W * s.C * o.ip[1] * o.ip[2]
+    return macs
+
+
+def cpu_baseline(compiled, max_threads=16, target_s_per_tier=2.5):
+    """Times the CPU oracle (oracle/tfhe_ref.c, the C twin; kind "port" -- the reference's own CPU path lives in absent
+    third-party wheels) on a bounded sample of the same workload and scales by the circuit's counts.  Sample, per parameter
+    tier the circuit uses: `threads x reps` FULL bootstraps (all n blind-rotate iterations; the key is random numbers of the
+    right shape, timing does not depend on its values) and as many key switches over the effective input dimension; plus one
+    3x3 ciphertext convolution, scaled by MACs.  About 15 s of CPU work."""
+    import numpy as np
     from oracle import ref_loader as R
     R.build()
-    R.lib().ref_set_num_threads(min(16, os.cpu_count() or 1))
-    ps = qm.compiled.param_set
+    R.lib().ref_set_num_threads(min(max_threads, os.cpu_count() or 1))
+    ps = compiled.param_set
     threads = R.lib().ref_num_threads()
     D = ps.D
-    S = R.gen_binary_key(1, D)
-    total_s = 0.0
-    detail = {}
-    for ti, t in enumerate(ps.tiers):
-        cnt = int(stats.pbs_count[ti])
+    deff = ps.input_dim or D
+    counts = compiled.pbs_counts()
+    total_s, detail = 0.0, {}
+    rng = np.random.default_rng(0)
+    t_begin = time.time()
+    for t in ps.tiers:
+        cnt = int(counts.get(t.name, 0))
         if cnt == 0:
             continue
-        s = R.gen_binary_key(2, n_prime)
-        bsk = R.bsk_gen(s, S, t.k, t.N, t.l, t.beta, 0.0, 4)
-        bskf = R.bsk_to_fourier(bsk)
-        small = np.random.default_rng(0).integers(0, 2 ** 64, (threads, n_prime + 1), dtype=np.uint64)
+        rows = (t.k + 1) * t.l
+        bskf = rng.standard_normal((t.n, rows, t.k + 1, t.N))
         table = (np.arange(16, dtype=np.int64)) << 58
-        R.pbs(small[:1], bskf, None, t.k, t.N, t.l, t.beta, table, 4, None, D)           # warm the FFT plan
+        small = rng.integers(0, 2 ** 64, (threads, t.n + 1), dtype=np.uint64)
+        t0 = time.time()
+        R.pbs(small, bskf, None, t.k, t.N, t.l, t.beta, table, 4, None, D)               # also warms the FFT plan
+        one = time.time() - t0
+        reps = int(max(1, min(8, target_s_per_tier / max(one, 1e-3))))
+        small = rng.integers(0, 2 ** 64, (threads * reps, t.n + 1), dtype=np.uint64)
         t0 = time.time()
         R.pbs(small, bskf, None, t.k, t.N, t.l, t.beta, table, 4, None, D)
-        t_pbs = (time.time() - t0) * (t.n / n_prime)                                      # seconds for `threads` bootstraps
-        ksk = np.random.default_rng(1).integers(0, 2 ** 64, (D, t.lk, n_prime + 1), dtype=np.uint64)
-        big = np.random.default_rng(2).integers(0, 2 ** 64, (threads, D + 1), dtype=np.uint64)
+        t_pbs = time.time() - t0
+        del bskf
+        ksk = rng.integers(0, 2 ** 64, (deff, t.lk, t.n + 1), dtype=np.uint64)
+        big = rng.integers(0, 2 ** 64, (threads * reps, deff + 1), dtype=np.uint64)
         t0 = time.time()
         R.keyswitch(big, ksk, t.betak)
-        t_ks = (time.time() - t0) * ((t.n + 1) / (n_prime + 1))
-        per_ct = (t_pbs + t_ks) / threads
-        detail[t.name] = dict(ms_per_pbs_per_core=per_ct * threads * 1e3 / 1.0, count=cnt)
+        t_ks = time.time() - t0
+        del ksk
+        per_ct = (t_pbs + t_ks) / (threads * reps)              # wall seconds per ciphertext with all threads busy
+        detail[t.name] = dict(ms_per_pbs_one_core=t_pbs / reps * 1e3, ms_per_keyswitch_one_core=t_ks / reps * 1e3, count=cnt, sample_cts=threads * reps)
         total_s += cnt * per_ct
-    # ciphertext convolution: one 8-channel 3x3 layer on a 6x6 map, scaled by MACs
     cin, cout, hw = 8, 8, 6
-    x = np.random.default_rng(3).integers(0, 2 ** 64, (cin, hw, hw, D + 1), dtype=np.uint64)
-    w = np.random.default_rng(4).integers(-7, 8, (cout, cin, 3, 3)).astype(np.int32)
+    x = rng.integers(0, 2 ** 64, (cin, hw, hw, deff + 1), dtype=np.uint64)
+    w = rng.integers(-7, 8, (cout, cin, 3, 3)).astype(np.int32)
     t0 = time.time()
-    R.conv2d(x, cin, hw, hw, D, w, 1, 1)
+    R.conv2d(x, cin, hw, hw, deff, w, 1, 1)
     macs = cout * cin * 9 * hw * hw
-    total_s += (time.time() - t0) * (stats.conv_macs / macs)
+    total_s += (time.time() - t0) * (conv_macs_of(compiled) / macs)
     return dict(value=1.0 / total_s, unit="images/s", cores=threads, kind="port",
-                sample=f"C twin (oracle/tfhe_ref.c, OpenMP {threads} threads): per tier {threads} bootstraps x {n_prime} of n blind-rotate "
-                       f"iterations + key switch onto {n_prime + 1} of n+1 columns, scaled linearly in n; one 8x8x3x3 ciphertext conv scaled by MACs",
-                s_per_image=total_s, per_tier=detail)
+                sample=f"C twin (oracle/tfhe_ref.c, OpenMP {threads} threads): per tier threads x reps full bootstraps (all n blind-rotate "
+                       f"iterations) + key switches over {deff} mask words, scaled by the circuit's counts; one 8x8x3x3 ciphertext conv scaled by MACs",
+                s_per_image=total_s, sample_wall_s=time.time() - t_begin, per_tier=detail)
 
 
-def _heartbeat(period=60.0):
-    """one stderr line a minute: a long encrypted run (config #5 takes ~12 min) must not look hung to the job runner"""
-    import threading
-    t0 = time.time()
-
+def _heartbeat(state, period=30.0):
+    """one stderr line every 30 s: a long encrypted run must not look hung to the job runner, and a killed run leaves its progress"""
     def beat():
         while True:
             time.sleep(period)
-            print(f"[bench] running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+            print(f"[bench] {time.time() - T_START:.0f} s: {state.get('phase', '?')}, passes done {state.get('passes', 0)}"
+                  + (f", last pass {state['last_s']:.2f} s" if "last_s" in state else ""), file=sys.stderr, flush=True)
     threading.Thread(target=beat, daemon=True).start()
 
 
+def plan_passes(req_warm, req_steps, warm_done, steps_done, pass_s, remaining_s):
+    """How many more warm-up passes and timed steps fit into `remaining_s` at `pass_s` per pass.  Timed steps take priority over
+    warm-up; at least one timed step always runs.  -> (warm_total, steps_total)."""
+    fit = int(max(0.0, remaining_s) // max(pass_s, 1e-6))
+    want_steps = max(0, req_steps - steps_done)
+    want_warm = max(0, req_warm - warm_done) if steps_done == 0 else 0
+    more_steps = min(want_steps, fit)
+    more_warm = min(want_warm, max(0, fit - more_steps))
+    if steps_done + more_steps == 0:
+        more_steps = 1
+    return warm_done + more_warm, steps_done + more_steps
+
+
+def self_launch(args_list, n, module="torch.distributed.run"):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks as CHILD processes (never an exec of a
+    process that has touched the GPU -- nothing here has) and hand back their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", module, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(args_list)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DCTFHE_BENCH_T0"] = repr(T_START)      # the children budget against the launcher's clock
+    return subprocess.call(cmd, env=env)
+
+
 def main():
-    _heartbeat()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "4")))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DCTFHE_BENCH_BATCH", "1")),
+                    help="encrypted images per GPU and step (default 1 = the reference's execute-mode case, run_homomorphic_eval.sh:22-23)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("DCTFHE_BENCH_BUDGET_S", "450")),
+                    help="wall-clock budget from process start; steps/warm-up are capped to fit (0 = no cap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tier-policy", default="exact", choices=["exact", "p_error"],
                     help="exact (the metric): outputs equal the integer circuit; p_error: the reference-style stochastic regime, p_error=0.01 per look-up (speed only)")
     ap.add_argument("--rounding-method", default="exact", choices=["exact", "approximate"])
     ap.add_argument("--config", default="r20_24_16", choices=sorted(CONFIGS), help="BASELINE.json config; the metric is quoted on r20_24_16")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher self-test (CPU, gloo): ranks shard a fake batch, all_gather it and rank 0 prints a JSON line; no GPU work")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
+    t_start = float(os.environ.get("DCTFHE_BENCH_T0", T_START))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dctfhe.sharding import gather_in_image_order, shard_indices
+
+    if args.launch_check:
+        dist.init_process_group("gloo")
+        B = args.batch_per_gpu
+        fake = torch.arange(B * world * 4, dtype=torch.float32).reshape(B * world, 4)
+        got = gather_in_image_order(fake[shard_indices(B * world, rank, world)], world)
+        ok = bool(torch.equal(got, fake))
+        flag = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "gather_in_image_order": bool(flag.item() > 0.5)}), flush=True)
+        dist.destroy_process_group()
+        return
+
+    state = {"phase": "setup", "passes": 0}
+    _heartbeat(state)
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from dctfhe import models
     from dctfhe.quantized_module import compile_brevitas_qat_model
-    from dctfhe.synthetic import synthetic_dct_batch
 
     B = args.batch_per_gpu
     # same circuit and same keys on every rank (seed-regenerated: no key traffic)
@@ -168,14 +247,32 @@ def main():
     calib = make_batch(16 if args.config == "r18_48_112" else 100, 7)
     model = getattr(models, factory)(bit_width=4, in_channels=in_ch, img_size=img, seed=0)
     rtb = 6 if args.rounding_method == "exact" else {"n_bits": 6, "method": "approximate"}
+    t0 = time.time()
     qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=rtb, p_error=0.01, device=local_rank, tier_policy=args.tier_policy)
+    compile_s = time.time() - t0
+
+    # CPU baseline: rank 0, N = 1 only, on its own thread while the GPU warms up (ctypes drops the GIL); joined before the timed region
+    cpu_box = {}
+    cpu_thread = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        def _cpu():
+            try:
+                cpu_box["res"] = cpu_baseline(qm.compiled)
+            except Exception as e:  # the baseline is a report, never the product path
+                cpu_box["res"] = {"error": repr(e)}
+        cpu_thread = threading.Thread(target=_cpu, daemon=True)
+        cpu_thread.start()
+
+    state["phase"] = "keygen"
     t0 = time.time()
     qm.fhe_circuit.keygen(seed=1)
     keygen_s = time.time() - t0
     stats = qm.statistics()
+    # seeded classifier with logits centred on the calibration features (clear circuit): labels differ between images
+    from dctfhe.synthetic import centre_classifier
+    centre_classifier(model, qm.forward(calib[:32], fhe="disable"))
 
     # this rank's shard of the global synthetic batch: image i -> rank i % world
-    from dctfhe.sharding import gather_in_image_order, shard_indices
     x_all = make_batch(B * world, 42)
     x = x_all[shard_indices(B * world, rank, world)]
     q = qm.quantize_input(x)
@@ -194,19 +291,60 @@ def main():
         torch.cuda.synchronize()
         qm._ctx.synchronize()
 
-    for _ in range(args.warmup):
+    def agree(warm, steps):
+        """every rank runs the same number of passes: the minimum over ranks"""
+        if world == 1:
+            return warm, steps
+        tt = torch.tensor([warm, steps], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return int(tt[0].item()), int(tt[1].item())
+
+    # ---- wall-clock budget -------------------------------------------------------------------------------------------------
+    reserve_s = 25.0                     # decrypt + clear circuit + JSON + teardown
+    budget = args.budget_s if args.budget_s > 0 else float("inf")
+
+    def remaining():
+        return budget - (time.time() - t_start) - reserve_s
+
+    interrupted = {"flag": False}
+
+    def on_term(signum, frame):          # a runner's SIGTERM: report what has been measured instead of dying silently
+        interrupted["flag"] = True
+    signal.signal(signal.SIGTERM, on_term)
+
+    warm_total, steps_total = args.warmup, args.steps
+    warm_done = 0
+    state["phase"] = "warm-up"
+    while warm_done < warm_total and not interrupted["flag"]:
+        t0 = time.time()
         sess.run()
+        dt = time.time() - t0
+        warm_done += 1
+        state.update(passes=warm_done, last_s=dt)
+        if warm_done == 1:               # plan the rest from the first pass
+            warm_total, steps_total = agree(*plan_passes(args.warmup, args.steps, 1, 0, dt, remaining()))
+    if cpu_thread is not None:
+        state["phase"] = "waiting for the CPU baseline"
+        cpu_thread.join()
+    state["phase"] = "timed steps"
     sync()
     t0 = time.time()
     timings = []
-    for _ in range(args.steps):
+    steps_done = 0
+    while steps_done < steps_total and not interrupted["flag"]:
+        ts = time.time()
         timings.append(sess.run(timing=True))
+        steps_done += 1
+        state.update(passes=warm_done + steps_done, last_s=time.time() - ts)
+        if warm_done == 0 and steps_done == 1:     # --warmup 0: plan from the first timed step
+            _, steps_total = agree(*plan_passes(0, args.steps, 0, 1, time.time() - ts, remaining()))
     sync()
     elapsed = time.time() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    state["phase"] = "decrypt + check"
 
     # decrypt this shard, classify in the clear (reference utils.py:22), gather logits over RCCL
     out = sess.download().reshape(-1, qm._keys.D + 1)
@@ -225,16 +363,16 @@ def main():
         all_logits = logits
 
     if rank == 0:
-        images = B * world * args.steps
+        steps = max(steps_done, 1)
+        images = B * world * steps
         value = images / elapsed
         ps = qm.compiled.param_set
         # dominant kernel: the bootstrap of the tier with the most time
-        tm = timings[-1]
         pbs_ms = [sum(t.pbs_ms[i] for t in timings) for i in range(len(ps.tiers))]
         dom = int(np.argmax(pbs_ms))
         td = ps.tiers[dom]
         launches = sum(t.pbs_launches[dom] for t in timings)
-        cts_dom = stats.pbs_count[dom] * B * args.steps
+        cts_dom = stats.pbs_count[dom] * B * steps
         avg_launch_s = pbs_ms[dom] * 1e-3 / max(launches, 1)
         cts_per_launch = cts_dom / max(launches, 1)
         N = td.N
@@ -250,29 +388,35 @@ def main():
         fp64_live = qm._ctx.fp64_peak()
         achieved_gbs = alg_bytes / avg_launch_s / 1e9
         achieved_tf = flops_per_pbs * cts_per_launch / avg_launch_s / 1e12
+        step_s = [t.total_ms * 1e-3 for t in timings]
+        wall_now = time.time() - t_start
         res = {
             "metric": "encrypted images/sec, ResNet-20 DCT-24x16^2 CIFAR-10" if args.config == "r20_24_16" else f"encrypted images/sec, {args.config}",
             "value": value,
             "unit": "images/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warm_done,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64 torus + f64 FFT",
             "data": "synthetic",
-            "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU, " +
+            "requested": {"steps": args.steps, "warmup": args.warmup, "budget_s": args.budget_s,
+                          "capped_by_budget": bool(steps < args.steps or warm_done < args.warmup), "interrupted": interrupted["flag"]},
+            "s_per_image": elapsed / (B * steps),
+            "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU and step, " +
                                    ("exact-evaluation tiers" if args.tier_policy == "exact" else "p_error=0.01 tiers (stochastic outputs, speed only)") +
                                    (", approximate rounding" if args.rounding_method == "approximate" else "") + ", rounding_threshold_bits=6, n_bits=5, bit_width=4",
                        "images_per_gpu": B, "global_batch": B * world, "parallelism": f"image-sharded x{world}",
-                       "s_per_image_per_gpu": elapsed / (B * args.steps),
+                       "s_per_image_per_gpu": elapsed / (B * steps),
+                       "step_s_min_max": [min(step_s), max(step_s)] if step_s else None,
                        "pbs_per_image": int(sum(stats.pbs_count)), "bit_steps_per_image": int(stats.bit_steps),
                        "table_lookups_per_image": int(stats.lut_sites), "conv_macs_per_image": int(stats.conv_macs),
-                       "max_bit_width": int(stats.max_bit_width), "keygen_s": keygen_s,
+                       "max_bit_width": int(stats.max_bit_width), "compile_s": compile_s, "keygen_s": keygen_s,
                        "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes),
-                       "images_per_s_pcie_inclusive": images / (elapsed + upload_s * args.steps),
+                       "images_per_s_pcie_inclusive": images / (elapsed + upload_s * steps),
                        "bit_exact_vs_integer_circuit": exact, "tier_policy": args.tier_policy, "rounding_method": args.rounding_method,
                        "outputs_equal_frac": float((diff == 0).mean()), "outputs_max_abs_diff": int(diff.max()),
                        "expected_boundary_flips_per_image": float(getattr(qm.compiled, "expected_boundary_flips_per_image", 0.0)),
@@ -291,17 +435,16 @@ def main():
                               "pbs_by_tier": {ps.tiers[i].name: pbs_ms[i] for i in range(len(ps.tiers))}},
             "algorithmic": {"bytes_per_image": stats.bytes_algorithmic, "key_bytes_per_pass": stats.key_bytes_per_pass,
                             "flops_f64_per_image": stats.flops_f64,
-                            "hbm_frac_whole_pipeline": (stats.bytes_algorithmic + stats.key_bytes_per_pass / B) * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                            "fp64_frac_whole_pipeline": stats.flops_f64 * B * args.steps / elapsed / 1e12 / FP64_SPEC_TFLOPS},
+                            "hbm_frac_whole_pipeline": (stats.bytes_algorithmic + stats.key_bytes_per_pass / B) * B * steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                            "fp64_frac_whole_pipeline": stats.flops_f64 * B * steps / elapsed / 1e12 / FP64_SPEC_TFLOPS},
+            "consistency": {"wall_since_start_s": wall_now, "timed_s": elapsed, "fits_in_driver_run": bool(elapsed <= wall_now)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                res["cpu_baseline"] = cpu_baseline(qm, stats)
+        if cpu_box.get("res") is not None:
+            res["cpu_baseline"] = cpu_box["res"]
+            if "value" in res["cpu_baseline"]:
                 res["cpu_baseline"]["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
-            except Exception as e:  # the baseline is a report, never the product path
-                res["cpu_baseline"] = {"error": repr(e)}
         res["reference_published_s_per_image"] = 565.0      # README.md:84, 96-core CPU; an anchor, not a vs_baseline (other hardware)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     qm.close()
     if world > 1:
         dist.destroy_process_group()

@@ -144,4 +144,38 @@ def tiny_resnet_q(in_channels=4, img_size=6, width=(6, 8), seed=0, bit_width=4):
                    classifier_w=rng.normal(0, 1.0 / math.sqrt(feat), size=(10, feat)), classifier_b=np.zeros(10))
 
 
+def float_forward(model, x):
+    """Float evaluation of the trunk as the reference's float twin computes it (models/backbone.py:47-58,182-184): no
+    quantisers, BatchNorm on its running statistics.  Used to check imported weights/topology against the reference."""
+    import torch
+    import torch.nn.functional as F
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+
+    def bn(b, h):
+        return F.batch_norm(h, t(b.mean), t(b.var), t(b.gamma), t(b.beta), False, 0.0, b.eps)
+
+    def conv(c, h):
+        return F.conv2d(h, t(c.weight), stride=c.stride, padding=c.pad)
+
+    h = bn(model.bn1, conv(model.conv1, t(x)))
+    if model.relu1:
+        h = F.relu(h)
+    for b in model.blocks:
+        o = bn(b.BN2, conv(b.C2, F.relu(bn(b.BN1, conv(b.C1, h)))))
+        sc = h if b.shortcut is None else bn(b.BNshortcut, conv(b.shortcut, h))
+        h = F.relu(o + sc)
+    return F.avg_pool2d(h, model.avgpool_kernel).flatten(1).numpy()
+
+
+def trunk_prefix(model, n_blocks, avgpool_kernel):
+    """The stem and the first `n_blocks` residual blocks of `model`, closed with the usual pooling + output quantiser: a
+    smaller circuit with the same layers, tiers and per-site precisions as the head of the full one (parity tests of
+    configurations whose full-size encrypted run takes many minutes).  The input may be any spatial crop."""
+    import dataclasses
+    blocks = list(model.blocks[:n_blocks])
+    feat = blocks[-1].C2.weight.shape[0] if blocks else model.conv1.weight.shape[0]
+    return dataclasses.replace(model, name=model.name + f"[:{n_blocks}]", blocks=blocks, avgpool_kernel=avgpool_kernel, final_feat_dim=feat,
+                               classifier_w=None, classifier_b=None)
+
+
 model_dict = dict(ResNet20qat=ResNet20QAT, ResNet18qat=ResNet18QAT)   # reference io_utils.py:5-10 (QAT entries)

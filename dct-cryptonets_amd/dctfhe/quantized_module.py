@@ -177,8 +177,10 @@ def _as_numpy(t):
 
 def compile_brevitas_qat_model(torch_model, torch_inputset, n_bits=5, configuration=None, rounding_threshold_bits=6, p_error=None,
                                verbose=False, device=0, param_set=None, tier_policy="exact", **kwargs):
-    """Same keyword surface as the call at reference homomorphic_eval.py:276-285.  `torch_model` is a
-    dctfhe.models.ResNetQ description (Brevitas modules cannot exist here: the package is absent).
+    """Same keyword surface as the call at reference homomorphic_eval.py:276-285.  `torch_model` is what the reference
+    passes -- the trunk `model.module.feature`, a torch.nn.Module walked by dctfhe.torch_import (duck-typed: the float
+    `ResNetDCT` and, where Brevitas exists, `ResNetQDCT` import unchanged) -- or a dctfhe.models.ResNetQ description.
+    `bit_width` (dctfhe addition): weight/activation width when the module does not say (`qconv_args`).
     rounding_threshold_bits: int (exact rounding) or {"n_bits": int, "method": "exact"|"approximate"} as the reference's
     README.md:95-114 suggests.  tier_policy: "exact" (default, outputs equal the integer circuit whatever p_error) or
     "p_error" (cheaper tiers whose look-ups fail with probability <= p_error; dctfhe addition)."""
@@ -188,6 +190,10 @@ def compile_brevitas_qat_model(torch_model, torch_inputset, n_bits=5, configurat
         rtb = rounding_threshold_bits["n_bits"]
     else:
         rtb = rounding_threshold_bits
+    from . import torch_import
+    bit_width = kwargs.pop("bit_width", None)
+    if torch_import.is_torch_module(torch_model):
+        torch_model = torch_import.from_torch_module(torch_model, bit_width=bit_width or 4)
     compiled = cc.compile_model(torch_model, _as_numpy(torch_inputset), rounding_threshold_bits=rtb, n_bits=n_bits,
                                 param_set=param_set, p_error=p_error, rounding_method=method, tier_policy=tier_policy)
     return QuantizedModule(compiled, device=device, verbose=verbose)
@@ -195,6 +201,11 @@ def compile_brevitas_qat_model(torch_model, torch_inputset, n_bits=5, configurat
 
 def compile_torch_model(torch_model, torch_inputset, n_bits=5, configuration=None, rounding_threshold_bits=6, p_error=None,
                         verbose=False, device=0, param_set=None, tier_policy="exact", **kwargs):
-    """PTQ twin of the above (reference homomorphic_eval.py:287-295); the circuit builder is the same."""
+    """PTQ twin of the above (reference homomorphic_eval.py:287-295): a float torch trunk (`ResNetDCT`), every weight and
+    activation quantised to `n_bits` post-training ([K] Concrete-ML's PTQ applies n_bits to all ops) unless `bit_width`
+    says otherwise; the circuit builder is the same."""
+    from . import torch_import
+    if torch_import.is_torch_module(torch_model):
+        kwargs.setdefault("bit_width", n_bits)
     return compile_brevitas_qat_model(torch_model, torch_inputset, n_bits, configuration, rounding_threshold_bits, p_error, verbose,
                                       device, param_set, tier_policy, **kwargs)

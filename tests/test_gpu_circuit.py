@@ -45,6 +45,21 @@ def test_execute_matches_integer_circuit(tiny):
     assert "round_lut" in qm.fhe_circuit.mlir
 
 
+def test_session_runs_twice_on_one_upload(tiny):
+    """dctfhe_session_run keeps its input: upload once, run twice (what bench.py does for warm-up + steps), both passes
+    equal the integer circuit (the allocator used to recycle the input buffer)."""
+    qm, calib = tiny
+    qm.fhe_circuit.keygen(seed=5)
+    q = qm.quantize_input(calib[20:23])
+    want = _oracle_out(qm, q)
+    sess = qm._session("execute", 3)
+    sess.upload(qm._keys.encrypt(qm.encode_input(q).reshape(-1), 4242))
+    for _ in range(2):
+        sess.run()
+        out = sess.download().reshape(-1, qm._keys.D + 1)
+        assert np.array_equal(qm.decode_output(qm._keys.decrypt(out).reshape(3, -1)), want)
+
+
 def test_ragged_batches(tiny):
     """batch sizes that do not fill the last workgroup / chunk"""
     qm, calib = tiny

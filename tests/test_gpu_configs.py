@@ -1,6 +1,14 @@
-"""Other BASELINE configs as parity cases: the circuit compiled for them, evaluated noise-free on the GPU scheduler
-(1-word ciphertexts) against the numpy integer circuit.  Encrypted runs of these sizes take minutes per image and
-are exercised by bench.py --config instead."""
+"""Every BASELINE config as a parity case on the encrypted HIP path.
+  * clear-mode circuit (1-word ciphertexts on the GPU scheduler) against the numpy integer circuit, configs #3 and #4;
+  * ENCRYPTED, full-size exact tiers, decrypt(run(encrypt(q))) == integer circuit on every output:
+      #2  ResNet-20 24x16^2, two images in one batch           (tests/test_gpu_resnet20.py)
+      #3  ResNet-20 3x32^2, one image (256 outputs)
+      #4  ResNet-18 3x32^2, one image (512 outputs)
+      #5  ResNet-18 48x112^2: one full-size image is ~9 minutes, so a circuit PREFIX -- the 1x1 stem without ReLU
+          (reference models/backbone.py:555-563 `relu1: False`) and the first stage of two 64-channel blocks -- on a
+          16x16 crop of the 112x112 DCT planes, same tiers, same per-site precisions.
+The label check uses the seeded classifier centred on the calibration features (dctfhe.synthetic.centre_classifier):
+labels differ between images, so comparing them checks something."""
 import numpy as np
 import pytest
 
@@ -13,11 +21,17 @@ def _rgb_batch(n, seed, size=32):
     return np.stack([tf(im) for im in synthetic.synthetic_images(n, seed)]).astype(np.float32)
 
 
+def _oracle(qm, q):
+    from oracle import circuit_ref
+    ref, overflow = circuit_ref.run_clear(qm.compiled.blob, qm.encode_input(q))
+    assert not overflow
+    return qm.decode_output(ref)
+
+
 @pytest.mark.parametrize("name,fn,conv_outputs,feat", [("R20 3x32^2 (config #3)", "ResNet20QAT", 860160, 256), ("R18 3x32^2 (config #4)", "ResNet18QAT", 614400, 512)])
 def test_clear_circuit_matches_oracle(name, fn, conv_outputs, feat):
     from dctfhe import compile as cc, models
     from dctfhe.quantized_module import QuantizedModule
-    from oracle import circuit_ref
     model = getattr(models, fn)(bit_width=4, in_channels=3, img_size=32)
     compiled = cc.compile_model(model, _rgb_batch(64, 7))      # the reference calibrates on 64-100 images (io_utils.py:72)
     convs = sum(compiled.tensors[o.dst].C * compiled.tensors[o.dst].H * compiled.tensors[o.dst].W for o in compiled.ops if o.type == cc.OP_CONV)
@@ -26,8 +40,52 @@ def test_clear_circuit_matches_oracle(name, fn, conv_outputs, feat):
     qm = QuantizedModule(compiled)
     try:
         q = qm.quantize_input(_rgb_batch(2, 42))
-        ref, overflow = circuit_ref.run_clear(compiled.blob, qm.encode_input(q))
-        assert not overflow
-        assert np.array_equal(qm.forward_quantized(q, "disable"), qm.decode_output(ref))
+        assert np.array_equal(qm.forward_quantized(q, "disable"), _oracle(qm, q))
+    finally:
+        qm.close()
+
+
+@pytest.mark.parametrize("name,fn,feat", [("R20 3x32^2 (config #3)", "ResNet20QAT", 256), ("R18 3x32^2 (config #4)", "ResNet18QAT", 512)])
+def test_encrypted_one_image_bit_exact(name, fn, feat):
+    from dctfhe import models
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    from dctfhe.synthetic import centre_classifier
+    model = getattr(models, fn)(bit_width=4, in_channels=3, img_size=32)
+    calib = _rgb_batch(100, 7)
+    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=6, p_error=0.01)
+    try:
+        centre_classifier(model, qm.forward(calib[:32], fhe="disable"))
+        x = _rgb_batch(8, 42)
+        q = qm.quantize_input(x)
+        want = _oracle(qm, q)
+        labels = (qm.dequantize_output(want) @ model.classifier_w.T + model.classifier_b).argmax(axis=1)
+        assert len(set(labels.tolist())) >= 3, labels            # the label check is not degenerate
+        qm.fhe_circuit.keygen(seed=1)
+        got = qm.forward_quantized(q[:1], "execute")
+        assert got.shape == (1, feat)
+        assert np.array_equal(got, want[:1]), (got, want[:1])
+        assert (qm.dequantize_output(got) @ model.classifier_w.T + model.classifier_b).argmax(axis=1)[0] == labels[0]
+    finally:
+        qm.close()
+
+
+def test_encrypted_config5_prefix_bit_exact():
+    """#5 ResNet-18 48x112^2: stem (1x1 48->64, no ReLU) + stage 1 (two 64-channel identity blocks) on a 16x16 crop."""
+    from dctfhe import frontend, models, synthetic
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=112, channels=48)
+    planes = np.stack([tf(im) for im in synthetic.synthetic_images(18, 7, size=96)]).astype(np.float32)     # [18, 48, 112, 112]
+    crops = planes[:, :, 40:56, 40:56]
+    model = models.ResNet18QAT(bit_width=4, in_channels=48, img_size=112)
+    assert model.relu1 is False and model.conv1.weight.shape == (64, 48, 1, 1)
+    prefix = models.trunk_prefix(model, n_blocks=2, avgpool_kernel=5)          # 16x16 -> floor(16/5) = 3x3 windows of 5x5
+    qm = compile_brevitas_qat_model(prefix, crops[:16], n_bits=5, rounding_threshold_bits=6, p_error=0.01)
+    try:
+        q = qm.quantize_input(crops[16:17])
+        want = _oracle(qm, q)
+        assert want.shape == (1, 64 * 3 * 3)
+        qm.fhe_circuit.keygen(seed=1)
+        got = qm.forward_quantized(q, "execute")
+        assert np.array_equal(got, want), (got, want)
     finally:
         qm.close()

@@ -37,15 +37,22 @@ def test_clear_mode_eight_images(r20):
     assert np.array_equal(r20.forward_quantized(q, "disable"), _oracle(r20, q))
 
 
-def test_execute_one_image_bit_exact(r20):
-    from dctfhe.synthetic import synthetic_dct_batch
-    x = synthetic_dct_batch(1, seed=42)
+def test_execute_two_images_bit_exact(r20):
+    """BASELINE config #2 (a batch in one session): two encrypted images, all 2 x 64 outputs and both labels"""
+    from dctfhe import models
+    from dctfhe.synthetic import centre_classifier, synthetic_dct_batch
+    x = synthetic_dct_batch(8, seed=42)
     q = r20.quantize_input(x)
     want = _oracle(r20, q)
+    model = models.ResNet20QAT(bit_width=4, in_channels=24, img_size=16)
+    centre_classifier(model, r20.forward(synthetic_dct_batch(32, seed=7), fhe="disable"))
+    labels = (r20.dequantize_output(want) @ model.classifier_w.T + model.classifier_b).argmax(axis=1)
+    assert len(set(labels.tolist())) >= 3, labels
     r20.fhe_circuit.keygen(seed=1)
-    got = r20.forward_quantized(q, "execute")
+    got = r20.forward_quantized(q[:2], "execute")
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "resnet20_execute_timing.json"), "w") as f:
         json.dump(r20.last_timing, f)
-    assert got.shape == (1, 64)
-    assert np.array_equal(got, want), (got, want)
+    assert got.shape == (2, 64)
+    assert np.array_equal(got, want[:2]), (got, want[:2])
+    assert np.array_equal((r20.dequantize_output(got) @ model.classifier_w.T + model.classifier_b).argmax(axis=1), labels[:2])

@@ -8,6 +8,8 @@ that would really call one of them is NOT used as an oracle.  What is captured:
   - cvfunctional.matrix2dct on seeded planes     (cvfunctional.py:37-57)
   - cvtransforms.SubsetDCT/Aggregate/NormalizeDCT on seeded tensors (cvtransforms.py:117-208)
   - the float twin models.backbone.ResNet20/ResNet18: conv output shapes, parameter counts
+  - the same twin under seeded weights (dctfhe.torch_import.seed_parameters): state-dict key names/shapes and the float
+    forward output on a seeded input
 Outputs are data only (inputs + expected outputs).
 """
 import importlib
@@ -90,6 +92,22 @@ def main():
         topo[f"{tag}_out"] = np.array(o.shape, np.int64)
         topo[f"{tag}_params"] = np.array(sum(p.numel() for p in m.parameters()), np.int64)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "topology_golden.npz"), **topo)
+
+    # the float twin under seeded weights: state-dict naming + forward output (tests/test_torch_import.py)
+    sys.path.insert(0, os.path.join(ROOT, "dct-cryptonets_amd"))
+    from dctfhe.torch_import import seed_parameters
+    ti = {}
+    for (fn, cin, size, tag) in [(bb.ResNet20, 24, 16, "r20_24_16"), (bb.ResNet18, 3, 32, "r18_3_32")]:
+        m = seed_parameters(fn(in_channels=cin, img_size=size), 11)
+        m.eval()
+        x = np.random.default_rng(12).normal(0, 1, (2, cin, size, size)).astype(np.float32)
+        with torch.no_grad():
+            y = m(torch.from_numpy(x))
+        sd = m.state_dict()
+        ti[f"{tag}_keys"] = np.array(list(sd.keys()))
+        ti[f"{tag}_shapes"] = np.array([";".join(map(str, v.shape)) for v in sd.values()])
+        ti[f"{tag}_x"], ti[f"{tag}_y"] = x, y.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "torch_import_golden.npz"), **ti)
     print("goldens written")
 
 
