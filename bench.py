@@ -265,7 +265,15 @@ def main():
 
     state["phase"] = "keygen"
     t0 = time.time()
-    qm.fhe_circuit.keygen(seed=1)
+    # one 256-bit key seed for the whole job: rank 0 draws it from the OS and broadcasts it; every rank regenerates the same
+    # client + evaluation keys from it on its own GPU (no key traffic) and encrypts from its own counter range
+    seed_t = torch.tensor(list(os.urandom(32)), dtype=torch.uint8)
+    if world > 1:
+        seed_t = seed_t.cuda()
+        dist.broadcast(seed_t, 0)
+        seed_t = seed_t.cpu()
+    qm.fhe_circuit.keygen(seed=bytes(seed_t.tolist()))
+    qm._keys.client.set_encrypt_counter(rank << 32)
     keygen_s = time.time() - t0
     stats = qm.statistics()
     # seeded classifier with logits centred on the calibration features (clear circuit): labels differ between images
@@ -278,7 +286,7 @@ def main():
     q = qm.quantize_input(x)
     phases = qm.encode_input(q)
     sess = qm._session("execute", B)
-    cts = qm._keys.encrypt(phases.reshape(-1), 1000 + rank)
+    cts = qm._keys.encrypt(phases.reshape(-1))
     t_up = time.time()
     sess.upload(cts)                      # inputs resident in HBM before the timed region
     upload_s = time.time() - t_up         # host -> device copy of the encrypted batch (reported, never part of `value`)
@@ -414,7 +422,7 @@ def main():
                        "step_s_min_max": [min(step_s), max(step_s)] if step_s else None,
                        "pbs_per_image": int(sum(stats.pbs_count)), "bit_steps_per_image": int(stats.bit_steps),
                        "table_lookups_per_image": int(stats.lut_sites), "conv_macs_per_image": int(stats.conv_macs),
-                       "max_bit_width": int(stats.max_bit_width), "compile_s": compile_s, "keygen_s": keygen_s,
+                       "max_bit_width": int(stats.max_bit_width), "compile_s": compile_s, "keygen_s": keygen_s, "key_seed": "32 bytes of os.urandom on rank 0, broadcast",
                        "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes),
                        "images_per_s_pcie_inclusive": images / (elapsed + upload_s * steps),
                        "bit_exact_vs_integer_circuit": exact, "tier_policy": args.tier_policy, "rounding_method": args.rounding_method,

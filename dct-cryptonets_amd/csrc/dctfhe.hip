@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,17 @@ struct dctfhe_ctx {
   hipDeviceProp_t prop;
 };
 
+// device buffer that frees itself unless released: every early return of an entry point cleans up after itself
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct TierKeys {
   dctfhe_tier t{};
   uint64_t* d_ksk = nullptr;     // [D][lk][n+1]
@@ -59,18 +71,45 @@ struct TierKeys {
   bool own_ksk = false;
   cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]; unroll 2: [3n/2 blocks] for the pair secret
   cplx* d_wtab = nullptr;        // unroll 2: e^{i pi m/N}, m < 2N, then e^{2 pi i k/8}, k < 8
-  uint8_t* d_spair = nullptr;    // unroll 2: derived secret (s1(1-s2), (1-s1)s2, s1 s2) per pair
   cplx* d_tw = nullptr;
 };
 
-struct dctfhe_keys {
+// CLIENT side: everything secret.  The whole handle is a function of (params, 32-byte seed): persist the seed to persist it.
+struct dctfhe_client_key {
   dctfhe_ctx* ctx = nullptr;
   dctfhe_params p{};
-  uint64_t seed = 0;
+  uint8_t seed[32] = {};
+  rng_key sec{}, pub{};          // ChaCha20 keys: secret (key bits, noise) and public (masks)
   uint8_t *d_S = nullptr, *d_s = nullptr;
+  uint8_t* d_spair[DCTFHE_MAX_TIERS] = {};   // unroll 2: derived secret (s1(1-s2), (1-s1)s2, s1 s2) per pair
+  uint64_t enc_calls = 0;        // every dctfhe_encrypt call draws from fresh streams
+  ~dctfhe_client_key() {
+    if (ctx) hipSetDevice(ctx->device);
+    hipFree(d_S); hipFree(d_s);
+    for (auto q : d_spair) hipFree(q);
+  }
+};
+
+// SERVER side: evaluation keys only (key-switch keys, Fourier bootstrap keys); nothing here depends on the secret at run time.
+struct dctfhe_eval_keys {
+  dctfhe_ctx* ctx = nullptr;
+  dctfhe_params p{};
   TierKeys tiers[DCTFHE_MAX_TIERS];
   uint64_t* d_dummy = nullptr;   // D+1 words, sink of padded bootstrap groups
+  ~dctfhe_eval_keys() {
+    if (ctx) hipSetDevice(ctx->device);
+    hipFree(d_dummy);
+    for (int i = 0; i < DCTFHE_MAX_TIERS; i++) {
+      TierKeys& tk = tiers[i];
+      if (tk.own_ksk) {
+        hipFree(tk.d_ksk); hipFree(tk.d_colsum); hipFree(tk.d_kskT);
+        if (tk.colsum_eff) { for (auto& kv : *tk.colsum_eff) hipFree(kv.second); delete tk.colsum_eff; }
+      }
+      hipFree(tk.d_bsk); hipFree(tk.d_tw); hipFree(tk.d_wtab);
+    }
+  }
 };
+using dctfhe_keys = dctfhe_eval_keys;   // the server-side code below says K for the evaluation keys
 
 enum { OP_CONV = 1, OP_ADD = 2, OP_SUMPOOL = 3, OP_LUT = 4 };
 struct Op {
@@ -87,6 +126,10 @@ struct dctfhe_circuit {
   std::vector<Op> ops;
   std::vector<void*> d_payload;  // per op, device copy of its payload (weights / tables)
   int input_tensor = 0, output_tensor = 0, max_bit_width = 0;
+  ~dctfhe_circuit() {
+    if (ctx) hipSetDevice(ctx->device);
+    for (void* p : d_payload) if (p) hipFree(p);
+  }
 };
 
 struct dctfhe_session {
@@ -108,6 +151,15 @@ struct dctfhe_session {
   // `simulate`: per-op noise (fraction of the torus) injected by the clear look-up kernel; empty = noise-free
   std::vector<double> sim_sigma;
   uint64_t sim_seed = 0, sim_run = 0;
+  // timing: events are created once and reused by every run; bootstraps per tier and image are fixed by the circuit
+  std::vector<hipEvent_t> ev_pool;
+  int64_t pbs_per_image[DCTFHE_MAX_TIERS] = {};
+  ~dctfhe_session() {
+    if (ctx) hipSetDevice(ctx->device);
+    for (auto& o : owned) hipFree(o.second);
+    for (hipEvent_t e : ev_pool) hipEventDestroy(e);
+    hipFree(d_digits); hipFree(d_bodies); hipFree(d_small); hipFree(d_bit_tables); hipFree(d_overflow);
+  }
 };
 
 // ------------------------------------------------------------------------------------------ kernel dispatch
@@ -140,6 +192,11 @@ static int tier_ppt(const dctfhe_tier& t) {
 
 static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st) {
   if (a.count == 0) return 0;
+  // the kernel's L2 warm-up contract (pbs_core.h): callers pad the key by PBS_PF_DIST iterations (eval_alloc does)
+  if (a.pf_parts != 0 && a.pf_parts < 8) return fail("bootstrap launch: pf_parts must be 0 or >= 8 (got %d)", a.pf_parts);
+  if (a.bsk_wrap < 0 || (a.bsk_wrap > 0 && t.unroll == 2)) return fail("bootstrap launch: bsk_wrap is a one-bit-kernel experiment switch");
+  if (!a.bsk || !a.tw || !a.cts_small || !a.out || !a.dummy || (t.unroll == 2 && !a.wtab)) return fail("bootstrap launch: null operand");
+  if (a.w < 0 || a.w > t.logN - 1) return fail("bootstrap launch: table of 2^%d entries does not fit N = 2^%d", a.w, t.logN);
 #define X(LN, K_, L_, P_)                                                                            \
   if (t.logN == LN && t.k == K_ && t.l == L_ && t.unroll == 1) {                                     \
     using G = pbs_geom<LN, K_, L_, P_>;                                                              \
@@ -267,8 +324,55 @@ static int check_params(const dctfhe_params* p) {
   return 0;
 }
 
-static int gen_bsk_std_chunk(dctfhe_keys* K, int tier, int i0, int ni, uint64_t* d_out) {
-  const dctfhe_tier& t = K->p.tiers[tier];
+// host-only validators: usable (and tested) without a GPU
+extern "C" int dctfhe_params_check(const dctfhe_params* params) {
+  if (!params) return fail("null parameters");
+  return check_params(params);
+}
+
+// ---- client key -----------------------------------------------------------------------------------
+static rng_key key_from_bytes(const uint8_t* b) {
+  rng_key k;
+  for (int i = 0; i < 8; i++) k.k[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+  return k;
+}
+
+extern "C" int dctfhe_client_key_create(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t* seed32, dctfhe_client_key** out) {
+  if (!ctx || !params || !seed32 || !out) return fail("dctfhe_client_key_create: null argument");
+  CHK(check_params(params));
+  HIPCHK(hipSetDevice(ctx->device));
+  std::unique_ptr<dctfhe_client_key> C(new dctfhe_client_key);
+  C->ctx = ctx; C->p = *params;
+  memcpy(C->seed, seed32, 32);
+  C->sec = key_from_bytes(seed32);
+  {  // the public (mask) key is one ChaCha20 block of the secret one: knowing it says nothing about the secret key
+    uint32_t o[16];
+    chacha20_block(C->sec, STREAM_PUBKEY, 0, o);
+    for (int i = 0; i < 8; i++) C->pub.k[i] = o[i];
+  }
+  hipStream_t st = ctx->stream;
+  const int D = params->D;
+  HIPCHK(hipMalloc(&C->d_S, D));
+  HIPCHK(hipMalloc(&C->d_s, params->n_max));
+  hipLaunchKernelGGL(k_gen_bits, dim3((D + 255) / 256), dim3(256), 0, st, C->sec, (uint64_t)STREAM_BIGKEY, C->d_S, D);
+  hipLaunchKernelGGL(k_gen_bits, dim3((params->n_max + 255) / 256), dim3(256), 0, st, C->sec, (uint64_t)STREAM_SMALLKEY, C->d_s, params->n_max);
+  HIPCHK(hipGetLastError());
+  for (int ti = 0; ti < params->n_tiers; ti++) {
+    const dctfhe_tier& t = params->tiers[ti];
+    if (t.unroll != 2) continue;
+    HIPCHK(hipMalloc(&C->d_spair[ti], (size_t)(3 * t.n / 2)));
+    hipLaunchKernelGGL(k_pair_secret, dim3((t.n / 2 + 255) / 256), dim3(256), 0, st, C->d_s, t.n, C->d_spair[ti]);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  *out = C.release();
+  return 0;
+}
+extern "C" int dctfhe_client_key_destroy(dctfhe_client_key* C) { delete C; return 0; }
+
+// standard-domain bootstrap key blocks [i0, i0+ni) of tier `tier` (regenerated from the client's streams whenever needed)
+static int gen_bsk_std_chunk(dctfhe_client_key* C, int tier, int i0, int ni, uint64_t* d_out) {
+  const dctfhe_tier& t = C->p.tiers[tier];
   const int N = 1 << t.logN, rows = (t.k + 1) * t.l;
   static bool attr_done = false;
   if (!attr_done) {
@@ -276,66 +380,56 @@ static int gen_bsk_std_chunk(dctfhe_keys* K, int tier, int i0, int ni, uint64_t*
     attr_done = true;
   }
   // unroll 2: the "secret" is the pair secret of 3n/2 bits, i0/ni count its blocks
-  const uint8_t* bits = t.unroll == 2 ? K->tiers[tier].d_spair : K->d_s;
-  hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, K->ctx->stream, bits, K->d_S, i0, t.k, N,
-                     t.l, t.beta, t.glwe_sigma, K->seed, (uint64_t)(STREAM_BSK_MASK + 2 * tier), d_out);
+  const uint8_t* bits = t.unroll == 2 ? C->d_spair[tier] : C->d_s;
+  hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, C->ctx->stream, bits, C->d_S, i0, t.k, N,
+                     t.l, t.beta, t.glwe_sigma, C->pub, C->sec, (uint64_t)(STREAM_BSK_MASK + 2 * tier), d_out);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint64_t seed, dctfhe_keys** out) {
+// ---- evaluation keys ------------------------------------------------------------------------------
+static size_t tier_bsk_blocks(const dctfhe_tier& t) { return (size_t)(t.unroll == 2 ? 3 * t.n / 2 : t.n); }
+static size_t tier_bsk_elems(const dctfhe_tier& t) {   // complex values of the Fourier key, without the warm-up padding
+  return tier_bsk_blocks(t) * (size_t)(t.k + 1) * t.l * (t.k + 1) * ((size_t)1 << (t.logN - 1));
+}
+static size_t tier_ksk_words(const dctfhe_params& p, const dctfhe_tier& t) { return (size_t)p.D * t.lk * (t.n + 1); }
+
+// allocate every array of the evaluation keys and fill what depends on the parameters only (twiddles, root tables)
+static int eval_alloc(dctfhe_ctx* ctx, const dctfhe_params* params, std::unique_ptr<dctfhe_eval_keys>& E) {
   CHK(check_params(params));
   HIPCHK(hipSetDevice(ctx->device));
-  auto* K = new dctfhe_keys;
-  K->ctx = ctx; K->p = *params; K->seed = seed;
+  E.reset(new dctfhe_eval_keys);
+  E->ctx = ctx; E->p = *params;
   hipStream_t st = ctx->stream;
   const int D = params->D;
-  HIPCHK(hipMalloc(&K->d_S, D));
-  HIPCHK(hipMalloc(&K->d_s, params->n_max));
-  HIPCHK(hipMalloc(&K->d_dummy, (size_t)(D + 1) * 8));
-  hipLaunchKernelGGL(k_gen_bits, dim3((D + 255) / 256), dim3(256), 0, st, seed, (uint64_t)STREAM_BIGKEY, K->d_S, D);
-  hipLaunchKernelGGL(k_gen_bits, dim3((params->n_max + 255) / 256), dim3(256), 0, st, seed, (uint64_t)STREAM_SMALLKEY, K->d_s, params->n_max);
-  HIPCHK(hipGetLastError());
+  HIPCHK(hipMalloc(&E->d_dummy, (size_t)(D + 1) * 8));
   for (int ti = 0; ti < params->n_tiers; ti++) {
     const dctfhe_tier& t = params->tiers[ti];
-    TierKeys& tk = K->tiers[ti];
+    TierKeys& tk = E->tiers[ti];
     tk.t = t;
-    // key-switch key
     if (t.ksk_share >= 0) {
-      tk.d_ksk = K->tiers[t.ksk_share].d_ksk;
-      tk.d_colsum = K->tiers[t.ksk_share].d_colsum;
-      tk.d_kskT = K->tiers[t.ksk_share].d_kskT;
-      tk.ncol_pad = K->tiers[t.ksk_share].ncol_pad;
-      tk.colsum_eff = K->tiers[t.ksk_share].colsum_eff;
+      const TierKeys& o = E->tiers[t.ksk_share];
+      tk.d_ksk = o.d_ksk; tk.d_colsum = o.d_colsum; tk.d_kskT = o.d_kskT; tk.ncol_pad = o.ncol_pad; tk.colsum_eff = o.colsum_eff;
     } else {
+      tk.own_ksk = true;
       tk.colsum_eff = new std::map<int, uint64_t*>();
       const size_t rows = (size_t)D * t.lk;
       HIPCHK(hipMalloc(&tk.d_ksk, rows * (t.n + 1) * 8));
       HIPCHK(hipMalloc(&tk.d_colsum, (size_t)(t.n + 1) * 8));
-      tk.own_ksk = true;
-      hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)rows), dim3(256), 0, st, K->d_S, K->d_s, t.n, t.lk, t.betak, t.lwe_sigma, seed,
-                         (uint64_t)(STREAM_KSK + 2 * ti), tk.d_ksk);
-      hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.d_colsum);
-      if (rows % 64 == 0 && rows <= (1u << 17)) {
+      // the i8 MFMA key switch reads digits as SIGNED bytes: offset digits in [0, 2^betak) need betak <= 7;
+      // wider gadgets and shapes the tiling does not cover go to the integer-VALU GEMM
+      if (rows % 64 == 0 && rows <= (1u << 17) && t.betak <= 7) {
         tk.ncol_pad = ((8 * (t.n + 1) + 127) / 128) * 128;
         HIPCHK(hipMalloc(&tk.d_kskT, (size_t)tk.ncol_pad * rows));
-        hipLaunchKernelGGL(k_ksk_to_limbs, dim3(4096), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.ncol_pad, tk.d_kskT);
       }
-      HIPCHK(hipGetLastError());
     }
-    // twiddles + Fourier bootstrap key
     std::vector<cplx> tw;
     CHK(make_twiddles(t, tw));
     HIPCHK(hipMalloc(&tk.d_tw, tw.size() * sizeof(cplx)));
     HIPCHK(hipMemcpyAsync(tk.d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    const int N = 1 << t.logN, M = N / 2, rows = (t.k + 1) * t.l;
-    const size_t per_bit_polys = (size_t)rows * (t.k + 1);
-    const int blocks = t.unroll == 2 ? 3 * t.n / 2 : t.n;     // key-bit-sized blocks; blocks read per iteration: unroll 2 -> 3
-    const int pad = PBS_PF_DIST * (t.unroll == 2 ? 3 : 1);
+    const int N = 1 << t.logN, M = N / 2;
     if (t.unroll == 2) {
-      HIPCHK(hipMalloc(&tk.d_spair, (size_t)blocks));
-      hipLaunchKernelGGL(k_pair_secret, dim3((t.n / 2 + 255) / 256), dim3(256), 0, st, K->d_s, t.n, tk.d_spair);
       std::vector<cplx> wt((size_t)2 * N + 8);
       const long double PI = 3.141592653589793238462643383279502884L;
       for (int m = 0; m < 2 * N; m++) { const long double a = PI * m / N; wt[m] = cmk((double)cosl(a), (double)sinl(a)); }
@@ -344,98 +438,221 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint6
       HIPCHK(hipMemcpyAsync(tk.d_wtab, wt.data(), wt.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
     }
-    // extra (zero) key blocks: the L2 warm-up of the last iterations reads past the key
-    HIPCHK(hipMalloc(&tk.d_bsk, (size_t)(blocks + pad) * per_bit_polys * M * sizeof(cplx)));
-    HIPCHK(hipMemsetAsync(tk.d_bsk + (size_t)blocks * per_bit_polys * M, 0, (size_t)pad * per_bit_polys * M * sizeof(cplx), st));
-    const int chunk = std::max(1, (int)std::min<size_t>(blocks, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
-    uint64_t* d_std = nullptr;
-    HIPCHK(hipMalloc(&d_std, (size_t)chunk * per_bit_polys * N * 8));
-    for (int i0 = 0; i0 < blocks; i0 += chunk) {
-      const int ni = std::min(chunk, blocks - i0);
-      CHK(gen_bsk_std_chunk(K, ti, i0, ni, d_std));
-      CHK(launch_bsk_fourier(t, d_std, (size_t)ni * per_bit_polys, tk.d_tw, tk.d_bsk + (size_t)i0 * per_bit_polys * M, st));
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(d_std));
+    // PBS_PF_DIST iterations' worth of extra (zero) key blocks: the L2 warm-up of the last iterations reads past the key
+    // (launch_pbs checks this contract: pbs_core.h, "L2 warm-up geometry")
+    const size_t per_block = (size_t)(t.k + 1) * t.l * (t.k + 1) * M;
+    const size_t pad = (size_t)PBS_PF_DIST * (t.unroll == 2 ? 3 : 1) * per_block;
+    HIPCHK(hipMalloc(&tk.d_bsk, (tier_bsk_elems(t) + pad) * sizeof(cplx)));
+    HIPCHK(hipMemsetAsync(tk.d_bsk + tier_bsk_elems(t), 0, pad * sizeof(cplx), st));
   }
   HIPCHK(hipStreamSynchronize(st));
-  *out = K;
   return 0;
 }
 
-extern "C" int dctfhe_keys_destroy(dctfhe_keys* K) {
-  if (!K) return 0;
-  hipSetDevice(K->ctx->device);
-  hipFree(K->d_S); hipFree(K->d_s); hipFree(K->d_dummy);
-  for (int i = 0; i < K->p.n_tiers; i++) {
-    if (K->tiers[i].own_ksk) {
-      hipFree(K->tiers[i].d_ksk); hipFree(K->tiers[i].d_colsum); if (K->tiers[i].d_kskT) hipFree(K->tiers[i].d_kskT);
-      if (K->tiers[i].colsum_eff) { for (auto& kv : *K->tiers[i].colsum_eff) hipFree(kv.second); delete K->tiers[i].colsum_eff; }
-    }
-    hipFree(K->tiers[i].d_bsk); hipFree(K->tiers[i].d_tw); hipFree(K->tiers[i].d_wtab); hipFree(K->tiers[i].d_spair);
+// what is derived from the key-switch keys once they are in place: column sums and the signed byte limbs
+static int eval_finish(dctfhe_eval_keys* E) {
+  hipStream_t st = E->ctx->stream;
+  for (int ti = 0; ti < E->p.n_tiers; ti++) {
+    const dctfhe_tier& t = E->p.tiers[ti];
+    TierKeys& tk = E->tiers[ti];
+    if (!tk.own_ksk) continue;
+    const size_t rows = (size_t)E->p.D * t.lk;
+    hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.d_colsum);
+    if (tk.d_kskT) hipLaunchKernelGGL(k_ksk_to_limbs, dim3(4096), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.ncol_pad, tk.d_kskT);
+    HIPCHK(hipGetLastError());
   }
-  delete K;
+  HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
 
-extern "C" int dctfhe_keys_export_secret(dctfhe_keys* K, uint8_t* big_key, uint8_t* small_key) {
-  HIPCHK(hipSetDevice(K->ctx->device));
-  HIPCHK(hipMemcpy(big_key, K->d_S, K->p.D, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(small_key, K->d_s, K->p.n_max, hipMemcpyDeviceToHost));
+extern "C" int dctfhe_eval_keys_generate(dctfhe_client_key* C, dctfhe_eval_keys** out) {
+  if (!C || !out) return fail("dctfhe_eval_keys_generate: null argument");
+  std::unique_ptr<dctfhe_eval_keys> E;
+  CHK(eval_alloc(C->ctx, &C->p, E));
+  hipStream_t st = C->ctx->stream;
+  const int D = C->p.D;
+  for (int ti = 0; ti < C->p.n_tiers; ti++) {
+    const dctfhe_tier& t = C->p.tiers[ti];
+    TierKeys& tk = E->tiers[ti];
+    if (tk.own_ksk) {
+      hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)((size_t)D * t.lk)), dim3(256), 0, st, C->d_S, C->d_s, t.n, t.lk, t.betak, t.lwe_sigma, C->pub, C->sec,
+                         (uint64_t)(STREAM_KSK + 2 * ti), tk.d_ksk);
+      HIPCHK(hipGetLastError());
+    }
+    const int N = 1 << t.logN, M = N / 2;
+    const size_t per_bit_polys = (size_t)(t.k + 1) * t.l * (t.k + 1);
+    const int blocks = (int)tier_bsk_blocks(t);
+    const int chunk = std::max(1, (int)std::min<size_t>(blocks, ((size_t)64 << 20) / (per_bit_polys * N * 8)));
+    DevBuf d_std;
+    HIPCHK(d_std.alloc((size_t)chunk * per_bit_polys * N * 8));
+    for (int i0 = 0; i0 < blocks; i0 += chunk) {
+      const int ni = std::min(chunk, blocks - i0);
+      CHK(gen_bsk_std_chunk(C, ti, i0, ni, d_std.as<uint64_t>()));
+      CHK(launch_bsk_fourier(t, d_std.as<uint64_t>(), (size_t)ni * per_bit_polys, tk.d_tw, tk.d_bsk + (size_t)i0 * per_bit_polys * M, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  CHK(eval_finish(E.get()));
+  *out = E.release();
   return 0;
 }
-extern "C" int dctfhe_keys_export_ksk(dctfhe_keys* K, int tier, uint64_t* out) {
+
+extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t* seed32, dctfhe_client_key** client, dctfhe_eval_keys** eval) {
+  if (!client || !eval) return fail("dctfhe_keygen: null output");
+  dctfhe_client_key* C = nullptr;
+  CHK(dctfhe_client_key_create(ctx, params, seed32, &C));
+  dctfhe_eval_keys* E = nullptr;
+  if (dctfhe_eval_keys_generate(C, &E)) { delete C; return -1; }
+  *client = C; *eval = E;
+  return 0;
+}
+extern "C" int dctfhe_eval_keys_destroy(dctfhe_eval_keys* E) { delete E; return 0; }
+
+// ---- evaluation-key persistence: header + params, then per tier its own key-switch key (u64) and its Fourier bootstrap key
+struct EvalBlobHeader { uint32_t magic, version; uint64_t total_bytes; dctfhe_params params; };
+static size_t eval_blob_size(const dctfhe_params& p) {
+  size_t n = sizeof(EvalBlobHeader);
+  for (int ti = 0; ti < p.n_tiers; ti++) {
+    const dctfhe_tier& t = p.tiers[ti];
+    if (t.ksk_share < 0) n += tier_ksk_words(p, t) * 8;
+    n += tier_bsk_elems(t) * sizeof(cplx);
+  }
+  return n;
+}
+extern "C" int dctfhe_eval_keys_export(dctfhe_eval_keys* E, void* buf, size_t capacity, size_t* size) {
+  if (!E || !size) return fail("dctfhe_eval_keys_export: null argument");
+  const size_t need = eval_blob_size(E->p);
+  *size = need;
+  if (!buf) return 0;                       // size query
+  if (capacity < need) return fail("dctfhe_eval_keys_export: buffer of %zu bytes, %zu needed", capacity, need);
+  HIPCHK(hipSetDevice(E->ctx->device));
+  HIPCHK(hipStreamSynchronize(E->ctx->stream));
+  EvalBlobHeader h{};
+  h.magic = 0x4b564544u /* 'DEVK' */; h.version = 1; h.total_bytes = need; h.params = E->p;
+  char* q = (char*)buf;
+  memcpy(q, &h, sizeof h); q += sizeof h;
+  for (int ti = 0; ti < E->p.n_tiers; ti++) {
+    const dctfhe_tier& t = E->p.tiers[ti];
+    if (t.ksk_share < 0) {
+      HIPCHK(hipMemcpy(q, E->tiers[ti].d_ksk, tier_ksk_words(E->p, t) * 8, hipMemcpyDeviceToHost));
+      q += tier_ksk_words(E->p, t) * 8;
+    }
+    HIPCHK(hipMemcpy(q, E->tiers[ti].d_bsk, tier_bsk_elems(t) * sizeof(cplx), hipMemcpyDeviceToHost));
+    q += tier_bsk_elems(t) * sizeof(cplx);
+  }
+  return 0;
+}
+extern "C" int dctfhe_eval_keys_import(dctfhe_ctx* ctx, const void* buf, size_t size, dctfhe_eval_keys** out) {
+  if (!ctx || !buf || !out) return fail("dctfhe_eval_keys_import: null argument");
+  if (size < sizeof(EvalBlobHeader)) return fail("evaluation-key blob too short");
+  EvalBlobHeader h;
+  memcpy(&h, buf, sizeof h);
+  if (h.magic != 0x4b564544u || h.version != 1) return fail("bad evaluation-key blob magic/version");
+  CHK(check_params(&h.params));
+  if (h.total_bytes != size || eval_blob_size(h.params) != size) return fail("evaluation-key blob is %zu bytes, its parameters need %zu", size, eval_blob_size(h.params));
+  std::unique_ptr<dctfhe_eval_keys> E;
+  CHK(eval_alloc(ctx, &h.params, E));
+  const char* q = (const char*)buf + sizeof h;
+  for (int ti = 0; ti < h.params.n_tiers; ti++) {
+    const dctfhe_tier& t = h.params.tiers[ti];
+    if (t.ksk_share < 0) {
+      HIPCHK(hipMemcpy(E->tiers[ti].d_ksk, q, tier_ksk_words(h.params, t) * 8, hipMemcpyHostToDevice));
+      q += tier_ksk_words(h.params, t) * 8;
+    }
+    HIPCHK(hipMemcpy(E->tiers[ti].d_bsk, q, tier_bsk_elems(t) * sizeof(cplx), hipMemcpyHostToDevice));
+    q += tier_bsk_elems(t) * sizeof(cplx);
+  }
+  CHK(eval_finish(E.get()));
+  *out = E.release();
+  return 0;
+}
+
+// ---- test / client views ---------------------------------------------------------------------------
+extern "C" int dctfhe_client_key_export_secret(dctfhe_client_key* C, uint8_t* big_key, uint8_t* small_key) {
+  HIPCHK(hipSetDevice(C->ctx->device));
+  HIPCHK(hipMemcpy(big_key, C->d_S, C->p.D, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(small_key, C->d_s, C->p.n_max, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int dctfhe_eval_keys_export_ksk(dctfhe_eval_keys* K, int tier, uint64_t* out) {
   if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
   const dctfhe_tier& t = K->p.tiers[tier];
   HIPCHK(hipSetDevice(K->ctx->device));
   HIPCHK(hipMemcpy(out, K->tiers[tier].d_ksk, (size_t)K->p.D * t.lk * (t.n + 1) * 8, hipMemcpyDeviceToHost));
   return 0;
 }
-extern "C" int dctfhe_keys_export_bsk(dctfhe_keys* K, int tier, uint64_t* out) {
-  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
-  const dctfhe_tier& t = K->p.tiers[tier];
-  HIPCHK(hipSetDevice(K->ctx->device));
+// the standard-domain bootstrap key, regenerated from the client's streams (what dctfhe_eval_keys_generate transformed)
+extern "C" int dctfhe_client_key_export_bsk(dctfhe_client_key* C, int tier, uint64_t* out) {
+  if (tier < 0 || tier >= C->p.n_tiers) return fail("tier out of range");
+  const dctfhe_tier& t = C->p.tiers[tier];
+  HIPCHK(hipSetDevice(C->ctx->device));
   const int N = 1 << t.logN;
-  const int blocks = t.unroll == 2 ? 3 * t.n / 2 : t.n;     // unroll 2: the key of the pair secret
+  const int blocks = (int)tier_bsk_blocks(t);     // unroll 2: the key of the pair secret
   const size_t words = (size_t)blocks * (t.k + 1) * t.l * (t.k + 1) * N;
-  uint64_t* d = nullptr;
-  HIPCHK(hipMalloc(&d, words * 8));
-  CHK(gen_bsk_std_chunk(K, tier, 0, blocks, d));
-  HIPCHK(hipStreamSynchronize(K->ctx->stream));
-  HIPCHK(hipMemcpy(out, d, words * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipFree(d));
+  DevBuf d;
+  HIPCHK(d.alloc(words * 8));
+  CHK(gen_bsk_std_chunk(C, tier, 0, blocks, d.as<uint64_t>()));
+  HIPCHK(hipStreamSynchronize(C->ctx->stream));
+  HIPCHK(hipMemcpy(out, d.p, words * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// CSPRNG views: `count` outputs of (key, stream, idx0..) -- on the host (no GPU needed: known-answer tests) and on the device
+extern "C" int dctfhe_rng_host(const uint8_t* key32, uint64_t stream, uint64_t idx0, size_t count, uint64_t* out) {
+  const rng_key k = key_from_bytes(key32);
+  for (size_t i = 0; i < count; i++) out[i] = rnd64(k, stream, idx0 + i);
+  return 0;
+}
+extern "C" int dctfhe_rng_device(dctfhe_ctx* ctx, const uint8_t* key32, uint64_t stream, uint64_t idx0, size_t count, uint64_t* out) {
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf d;
+  HIPCHK(d.alloc(count * 8));
+  hipLaunchKernelGGL(k_rng_fill, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, key_from_bytes(key32), stream, idx0, d.as<uint64_t>(), count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d.p, count * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ client ops
-extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* phases, size_t count, uint64_t seed, uint64_t* cts) {
+extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* phases, size_t count, uint64_t* cts) {
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
-  const int D = K->p.D;
-  uint64_t *d_ph = nullptr, *d_ct = nullptr;
-  HIPCHK(hipMalloc(&d_ph, count * 8));
-  HIPCHK(hipMalloc(&d_ct, count * (size_t)(D + 1) * 8));
-  HIPCHK(hipMemcpyAsync(d_ph, phases, count * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, K->p.input_dim > 0 ? K->p.input_dim : D, d_ph, K->p.input_sigma, seed, d_ct);
+  const int D = C->p.D;
+  DevBuf d_ph, d_ct;
+  HIPCHK(d_ph.alloc(count * 8));
+  HIPCHK(d_ct.alloc(count * (size_t)(D + 1) * 8));
+  HIPCHK(hipMemcpyAsync(d_ph.p, phases, count * 8, hipMemcpyHostToDevice, ctx->stream));
+  // fresh streams per call: a (mask, noise) pair is never drawn twice under one key
+  const uint64_t stream = (uint64_t)STREAM_ENC + ((++C->enc_calls) << 16);
+  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, D, C->p.input_dim > 0 ? C->p.input_dim : D, d_ph.as<uint64_t>(),
+                     C->p.input_sigma, C->pub, C->sec, stream, d_ct.as<uint64_t>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(cts, d_ct, count * (size_t)(D + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(cts, d_ct.p, count * (size_t)(D + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hipFree(d_ph); hipFree(d_ct);
   return 0;
 }
-extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* cts, size_t count, uint64_t* phases) {
+// two processes that hold the same client key (ranks of one job) must not draw the same encryption streams: each sets
+// its own counter range, e.g. rank << 32
+extern "C" int dctfhe_client_key_set_encrypt_counter(dctfhe_client_key* C, uint64_t next_call) {
+  if (!C) return fail("null client key");
+  if (next_call >= (1ULL << 47)) return fail("encrypt counter out of range");
+  C->enc_calls = next_call;
+  return 0;
+}
+extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* cts, size_t count, uint64_t* phases) {
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
-  const int D = K->p.D;
-  uint64_t *d_ph = nullptr, *d_ct = nullptr;
-  HIPCHK(hipMalloc(&d_ph, count * 8));
-  HIPCHK(hipMalloc(&d_ct, count * (size_t)(D + 1) * 8));
-  HIPCHK(hipMemcpyAsync(d_ct, cts, count * (size_t)(D + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lwe_phase, dim3((unsigned)count), dim3(256), 0, ctx->stream, K->d_S, D, d_ct, d_ph);
+  const int D = C->p.D;
+  DevBuf d_ph, d_ct;
+  HIPCHK(d_ph.alloc(count * 8));
+  HIPCHK(d_ct.alloc(count * (size_t)(D + 1) * 8));
+  HIPCHK(hipMemcpyAsync(d_ct.p, cts, count * (size_t)(D + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_lwe_phase, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, D, d_ct.as<uint64_t>(), d_ph.as<uint64_t>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(phases, d_ph, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(phases, d_ph.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  hipFree(d_ph); hipFree(d_ct);
   return 0;
 }
 
@@ -443,12 +660,18 @@ extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_keys* K, const uint64_t* c
 struct Timers {
   hipStream_t st;
   bool on;
+  std::vector<hipEvent_t>* pool;     // owned by the session (or by nobody: primitives pass on = false)
   struct Span { hipEvent_t a, b; int cat; };
   std::vector<Span> spans;
+  size_t used = 0;
+  hipEvent_t take() {
+    if (used == pool->size()) { hipEvent_t e; hipEventCreate(&e); pool->push_back(e); }
+    return (*pool)[used++];
+  }
   int begin(int cat) {
     if (!on) return -1;
     Span s; s.cat = cat;
-    hipEventCreate(&s.a); hipEventCreate(&s.b);
+    s.a = take(); s.b = take();
     hipEventRecord(s.a, st);
     spans.push_back(s);
     return (int)spans.size() - 1;
@@ -523,7 +746,7 @@ static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, in
 static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 16384)); }
 
 // exact rounding + table look-up on `count` ciphertexts, in place on d_work (already shifted / offset)
-struct LutScratch { uint8_t* digits; uint64_t* bodies; uint64_t* small; int64_t* bit_tables; size_t chunk; };
+struct LutScratch { uint8_t* digits = nullptr; uint64_t* bodies = nullptr; uint64_t* small = nullptr; int64_t* bit_tables = nullptr; size_t chunk = 0; };
 // rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe)
 static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, uint64_t* d_work, size_t count, int p, int r,
                          const int64_t* d_tables, int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm, int deff = 0) {
@@ -561,122 +784,136 @@ static int alloc_lut_scratch(dctfhe_keys* K, size_t chunk, LutScratch* sc) {
 }
 static void free_lut_scratch(LutScratch* sc) {
   hipFree(sc->digits); hipFree(sc->bodies); hipFree(sc->small); hipFree(sc->bit_tables);
+  sc->digits = nullptr; sc->bodies = nullptr; sc->small = nullptr; sc->bit_tables = nullptr;
 }
+struct LutScratchOwner { LutScratch s{}; ~LutScratchOwner() { free_lut_scratch(&s); } };
 
 // ------------------------------------------------------------------------------------------ primitives on host buffers
-extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, int deff,
-                                       uint64_t* cts_small);
-extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, uint64_t* cts_small) {
-  return dctfhe_keyswitch_prefix(ctx, K, tier, cts, count, shift, 0, cts_small);
-}
-extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts, size_t count, int shift, int deff,
+extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, const uint64_t* cts, size_t count, int shift, int deff,
                                        uint64_t* cts_small) {
+  if (!ctx || !K) return fail("dctfhe_keyswitch: null handle");
   if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
   if (deff < 0 || deff > K->p.D) return fail("deff out of range");
+  if (shift < 0 || shift > 63) return fail("shift out of range");
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
   const dctfhe_tier& t = K->p.tiers[tier];
   const size_t L = (size_t)K->p.D + 1;
-  uint64_t *d_in, *d_small, *d_bodies; uint8_t* d_dig;
-  HIPCHK(hipMalloc(&d_in, count * L * 8));
-  HIPCHK(hipMalloc(&d_small, count * (size_t)(t.n + 1) * 8));
-  HIPCHK(hipMalloc(&d_bodies, count * 8));
-  HIPCHK(hipMalloc(&d_dig, count * (size_t)K->p.D * t.lk));
-  HIPCHK(hipMemcpy(d_in, cts, count * L * 8, hipMemcpyHostToDevice));
-  CHK(dev_keyswitch(K, tier, d_in, count, shift, d_dig, d_bodies, d_small, nullptr, deff));
+  DevBuf d_in, d_small, d_bodies, d_dig;
+  HIPCHK(d_in.alloc(count * L * 8));
+  HIPCHK(d_small.alloc(count * (size_t)(t.n + 1) * 8));
+  HIPCHK(d_bodies.alloc(count * 8));
+  HIPCHK(d_dig.alloc(count * (size_t)K->p.D * t.lk));
+  HIPCHK(hipMemcpy(d_in.p, cts, count * L * 8, hipMemcpyHostToDevice));
+  CHK(dev_keyswitch(K, tier, d_in.as<uint64_t>(), count, shift, d_dig.as<uint8_t>(), d_bodies.as<uint64_t>(), d_small.as<uint64_t>(), nullptr, deff));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(cts_small, d_small, count * (size_t)(t.n + 1) * 8, hipMemcpyDeviceToHost));
-  hipFree(d_in); hipFree(d_small); hipFree(d_bodies); hipFree(d_dig);
+  HIPCHK(hipMemcpy(cts_small, d_small.p, count * (size_t)(t.n + 1) * 8, hipMemcpyDeviceToHost));
   return 0;
 }
+extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, const uint64_t* cts, size_t count, int shift, uint64_t* cts_small) {
+  return dctfhe_keyswitch_prefix(ctx, K, tier, cts, count, shift, 0, cts_small);
+}
 
-extern "C" int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_keys* K, int tier, const uint64_t* cts_small, size_t count, const int64_t* tables, int ntab,
+extern "C" int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, const uint64_t* cts_small, size_t count, const int64_t* tables, int ntab,
                           int w, const int32_t* table_idx, uint64_t* cts_out) {
+  if (!ctx || !K) return fail("dctfhe_pbs: null handle");
   if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  if (ntab < 1 || w < 0) return fail("dctfhe_pbs: need at least one table and w >= 0");
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
   const dctfhe_tier& t = K->p.tiers[tier];
   if (w > t.logN - 1) return fail("table of 2^%d entries does not fit N = 2^%d", w, t.logN);
+  if (table_idx)
+    for (size_t i = 0; i < count; i++)
+      if (table_idx[i] < 0 || table_idx[i] >= ntab) return fail("table_idx[%zu] = %d out of range (%d tables)", i, table_idx[i], ntab);
   const size_t L = (size_t)K->p.D + 1;
-  uint64_t *d_small, *d_out; int64_t* d_tab; int32_t* d_idx = nullptr;
-  HIPCHK(hipMalloc(&d_small, count * (size_t)(t.n + 1) * 8));
-  HIPCHK(hipMalloc(&d_out, count * L * 8));
-  HIPCHK(hipMalloc(&d_tab, ((size_t)ntab << w) * 8));
-  HIPCHK(hipMemcpy(d_small, cts_small, count * (size_t)(t.n + 1) * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_tab, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
+  DevBuf d_small, d_out, d_tab, d_idx;
+  HIPCHK(d_small.alloc(count * (size_t)(t.n + 1) * 8));
+  HIPCHK(d_out.alloc(count * L * 8));
+  HIPCHK(d_tab.alloc(((size_t)ntab << w) * 8));
+  HIPCHK(hipMemcpy(d_small.p, cts_small, count * (size_t)(t.n + 1) * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_tab.p, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
   if (table_idx) {
-    HIPCHK(hipMalloc(&d_idx, count * 4));
-    HIPCHK(hipMemcpy(d_idx, table_idx, count * 4, hipMemcpyHostToDevice));
+    HIPCHK(d_idx.alloc(count * 4));
+    HIPCHK(hipMemcpy(d_idx.p, table_idx, count * 4, hipMemcpyHostToDevice));
   }
-  CHK(dev_pbs(K, tier, d_small, count, d_tab, w, d_idx, 1, 1, 0, d_out, 0, 0, nullptr));
+  CHK(dev_pbs(K, tier, d_small.as<uint64_t>(), count, d_tab.as<int64_t>(), w, d_idx.as<int32_t>(), 1, 1, 0, d_out.as<uint64_t>(), 0, 0, nullptr));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(cts_out, d_out, count * L * 8, hipMemcpyDeviceToHost));
-  hipFree(d_small); hipFree(d_out); hipFree(d_tab); if (d_idx) hipFree(d_idx);
+  HIPCHK(hipMemcpy(cts_out, d_out.p, count * L * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
-extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_keys* K, int bit_tier, int tab_tier, const uint64_t* cts, size_t count, int p, int r,
+extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int bit_tier, int tab_tier, const uint64_t* cts, size_t count, int p, int r,
                                 const int64_t* tables, int ntab, int w, const int32_t* table_idx, uint64_t* cts_out) {
+  if (!ctx || !K) return fail("dctfhe_round_lut: null handle");
   if (tab_tier < 0 || tab_tier >= K->p.n_tiers || (r > 0 && (bit_tier < 0 || bit_tier >= K->p.n_tiers))) return fail("tier out of range");
+  if (p < 1 || p > 62 || r < 0 || r >= p) return fail("need 1 <= p <= 62 and 0 <= r < p");
   if (w != p - r) return fail("w must equal p - r");
+  if (w > K->p.tiers[tab_tier].logN - 1) return fail("table of 2^%d entries does not fit tier %d", w, tab_tier);
+  if (ntab < 1) return fail("need at least one table");
   if (count == 0) return 0;
+  if (table_idx)
+    for (size_t i = 0; i < count; i++)
+      if (table_idx[i] < 0 || table_idx[i] >= ntab) return fail("table_idx[%zu] = %d out of range (%d tables)", i, table_idx[i], ntab);
   HIPCHK(hipSetDevice(ctx->device));
   const size_t L = (size_t)K->p.D + 1;
-  uint64_t* d_work; int64_t* d_tab; int32_t* d_idx = nullptr;
-  HIPCHK(hipMalloc(&d_work, count * L * 8));
-  HIPCHK(hipMalloc(&d_tab, ((size_t)ntab << w) * 8));
-  HIPCHK(hipMemcpy(d_work, cts, count * L * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_tab, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
+  DevBuf d_work, d_tab, d_idx;
+  HIPCHK(d_work.alloc(count * L * 8));
+  HIPCHK(d_tab.alloc(((size_t)ntab << w) * 8));
+  HIPCHK(hipMemcpy(d_work.p, cts, count * L * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_tab.p, tables, ((size_t)ntab << w) * 8, hipMemcpyHostToDevice));
   if (table_idx) {
-    HIPCHK(hipMalloc(&d_idx, count * 4));
-    HIPCHK(hipMemcpy(d_idx, table_idx, count * 4, hipMemcpyHostToDevice));
+    HIPCHK(d_idx.alloc(count * 4));
+    HIPCHK(hipMemcpy(d_idx.p, table_idx, count * 4, hipMemcpyHostToDevice));
   }
-  LutScratch sc;
-  CHK(alloc_lut_scratch(K, std::min<size_t>(count, 4096), &sc));
+  LutScratchOwner sc;
+  CHK(alloc_lut_scratch(K, std::min<size_t>(count, 4096), &sc.s));
   if (r > 0) {
-    hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work, d_work, count, L, 0, 1ULL << (63 - p + r - 1));
+    hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work.as<uint64_t>(), d_work.as<uint64_t>(), count, L, 0, 1ULL << (63 - p + r - 1));
     HIPCHK(hipGetLastError());
   }
-  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work, count, p, r, d_tab, w, d_idx, 1, 1, sc, nullptr));
+  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work.as<uint64_t>(), count, p, r, d_tab.as<int64_t>(), w, d_idx.as<int32_t>(), 1, 1, sc.s, nullptr));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(cts_out, d_work, count * L * 8, hipMemcpyDeviceToHost));
-  free_lut_scratch(&sc);
-  hipFree(d_work); hipFree(d_tab); if (d_idx) hipFree(d_idx);
+  HIPCHK(hipMemcpy(cts_out, d_work.p, count * L * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
 extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int batch, int Cin, int H, int W, const int8_t* weight, int Cout,
                              int KH, int KW, int stride, int pad, uint64_t* out) {
+  if (!ctx) return fail("dctfhe_conv2d: null context");
+  if (D < 0 || batch < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0) return fail("dctfhe_conv2d: bad geometry");
+  if (H + 2 * pad < KH || W + 2 * pad < KW) return fail("dctfhe_conv2d: kernel larger than the padded input");
   HIPCHK(hipSetDevice(ctx->device));
   const size_t L = (size_t)D + 1;
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const size_t nin = (size_t)batch * Cin * H * W * L, nout = (size_t)batch * Cout * Ho * Wo * L, nw = (size_t)Cout * Cin * KH * KW;
-  uint64_t *d_in, *d_out; int8_t* d_w;
-  HIPCHK(hipMalloc(&d_in, nin * 8));
-  HIPCHK(hipMalloc(&d_out, nout * 8));
-  HIPCHK(hipMalloc(&d_w, nw));
-  HIPCHK(hipMemcpy(d_in, in, nin * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(d_w, weight, nw, hipMemcpyHostToDevice));
-  CHK(dev_conv2d(ctx->stream, d_in, batch, Cin, H, W, L, d_w, Cout, KH, KW, stride, pad, d_out));
+  DevBuf d_in, d_out, d_w;
+  HIPCHK(d_in.alloc(nin * 8));
+  HIPCHK(d_out.alloc(nout * 8));
+  HIPCHK(d_w.alloc(nw));
+  HIPCHK(hipMemcpy(d_in.p, in, nin * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_w.p, weight, nw, hipMemcpyHostToDevice));
+  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, d_w.as<int8_t>(), Cout, KH, KW, stride, pad, d_out.as<uint64_t>()));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipMemcpy(out, d_out, nout * 8, hipMemcpyDeviceToHost));
-  hipFree(d_in); hipFree(d_out); hipFree(d_w);
+  HIPCHK(hipMemcpy(out, d_out.p, nout * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------ circuit
 struct BlobHeader { uint32_t magic, version; int32_t n_tensors, n_ops, input_tensor, output_tensor, max_bit_width, reserved; };
 
-extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t size, dctfhe_circuit** out) {
+// parse + validate a circuit blob on the host (no GPU): header, tensor table, op records, payload ranges, per-op shapes
+static int parse_circuit(const void* blob, size_t size, dctfhe_circuit* c) {
+  if (!blob) return fail("null circuit blob");
   if (size < sizeof(BlobHeader)) return fail("circuit blob too short");
   BlobHeader h;
   memcpy(&h, blob, sizeof h);
   if (h.magic != 0x46544344u /* 'DCTF' */ || h.version != 1) return fail("bad circuit blob magic/version");
+  if (h.n_tensors < 1 || h.n_ops < 0 || h.n_tensors > (1 << 20) || h.n_ops > (1 << 20)) return fail("circuit blob: bad tensor/op count");
   const size_t need = sizeof h + (size_t)h.n_tensors * sizeof(TensorShape) + (size_t)h.n_ops * sizeof(Op);
-  if (h.n_tensors < 1 || h.n_ops < 0 || size < need) return fail("circuit blob truncated");
-  HIPCHK(hipSetDevice(ctx->device));
-  auto* c = new dctfhe_circuit;
-  c->ctx = ctx;
+  if (size < need) return fail("circuit blob truncated");
+  auto bad_t = [&](int t) { return t < 0 || t >= h.n_tensors; };
+  if (bad_t(h.input_tensor) || bad_t(h.output_tensor)) return fail("circuit blob: input/output tensor id out of range");
   c->tensors.resize(h.n_tensors);
   c->ops.resize(h.n_ops);
   const char* p = (const char*)blob + sizeof h;
@@ -684,27 +921,70 @@ extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t siz
   p += (size_t)h.n_tensors * sizeof(TensorShape);
   memcpy(c->ops.data(), p, (size_t)h.n_ops * sizeof(Op));
   c->input_tensor = h.input_tensor; c->output_tensor = h.output_tensor; c->max_bit_width = h.max_bit_width;
-  c->d_payload.assign(h.n_ops, nullptr);
+  for (const TensorShape& t : c->tensors)
+    if (t.C < 1 || t.H < 1 || t.W < 1) return fail("circuit blob: empty tensor shape");
   for (int i = 0; i < h.n_ops; i++) {
     const Op& o = c->ops[i];
-    auto bad_t = [&](int t) { return t < 0 || t >= h.n_tensors; };
-    if (bad_t(o.src0) || bad_t(o.dst) || (o.type == OP_ADD && bad_t(o.src1))) { delete c; return fail("op %d: tensor id out of range", i); }
+    if (o.type < OP_CONV || o.type > OP_LUT) return fail("op %d: unknown type %d", i, o.type);
+    if (bad_t(o.src0) || bad_t(o.dst) || (o.type == OP_ADD && bad_t(o.src1))) return fail("op %d: tensor id out of range", i);
+    if (o.payload_len < 0 || (o.payload_len > 0 && (o.payload_off < (int64_t)need || (size_t)o.payload_off + (size_t)o.payload_len > size)))
+      return fail("op %d: payload out of range", i);
+    const TensorShape& a = c->tensors[o.src0];
+    const TensorShape& d = c->tensors[o.dst];
+    switch (o.type) {
+      case OP_CONV: {
+        const int Cout = o.ip[0], KH = o.ip[1], KW = o.ip[2], st = o.ip[3], pad = o.ip[4];
+        if (Cout < 1 || KH < 1 || KW < 1 || st < 1 || pad < 0 || a.H + 2 * pad < KH || a.W + 2 * pad < KW) return fail("op %d: bad convolution geometry", i);
+        if (d.C != Cout || d.H != (a.H + 2 * pad - KH) / st + 1 || d.W != (a.W + 2 * pad - KW) / st + 1) return fail("op %d: convolution output shape mismatch", i);
+        if (o.payload_len != (int64_t)Cout * a.C * KH * KW) return fail("op %d: weight payload of %lld bytes, expected %lld", i, (long long)o.payload_len, (long long)Cout * a.C * KH * KW);
+        break;
+      }
+      case OP_ADD: {
+        const TensorShape& b2 = c->tensors[o.src1];
+        if (a.C != b2.C || a.H != b2.H || a.W != b2.W || a.C != d.C || a.H != d.H || a.W != d.W) return fail("op %d: add operands differ in shape", i);
+        break;
+      }
+      case OP_SUMPOOL: {
+        const int K = o.ip[0];
+        if (K < 1 || d.C != a.C || d.H != a.H / K || d.W != a.W / K || d.H < 1 || d.W < 1) return fail("op %d: bad pooling geometry", i);
+        break;
+      }
+      case OP_LUT: {
+        const int pp = o.ip[0], r = o.ip[1], w = o.ip[2], shift = o.ip[3], ntab = o.ip[6];
+        if (pp < 1 || pp > 62 || r < 0 || r >= pp || w != pp - r || shift < 0 || shift > 63) return fail("op %d: bad look-up precision (p=%d r=%d w=%d shift=%d)", i, pp, r, w, shift);
+        if (ntab != 1 && ntab != a.C) return fail("op %d: %d tables for %d channels", i, ntab, a.C);
+        if (o.payload_len != ((int64_t)ntab << w) * 8) return fail("op %d: table payload of %lld bytes, expected %lld", i, (long long)o.payload_len, (long long)(((int64_t)ntab << w) * 8));
+        if (a.C != d.C || a.H != d.H || a.W != d.W) return fail("op %d: look-up changes the shape", i);
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int dctfhe_circuit_validate(const void* blob, size_t size) {
+  dctfhe_circuit c;
+  return parse_circuit(blob, size, &c);
+}
+
+extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t size, dctfhe_circuit** out) {
+  if (!ctx || !out) return fail("dctfhe_circuit_load: null argument");
+  std::unique_ptr<dctfhe_circuit> c(new dctfhe_circuit);
+  CHK(parse_circuit(blob, size, c.get()));
+  HIPCHK(hipSetDevice(ctx->device));
+  c->ctx = ctx;
+  c->d_payload.assign(c->ops.size(), nullptr);
+  for (size_t i = 0; i < c->ops.size(); i++) {
+    const Op& o = c->ops[i];
     if (o.payload_len > 0) {
-      if (o.payload_off < 0 || (size_t)(o.payload_off + o.payload_len) > size) { delete c; return fail("op %d: payload out of range", i); }
       HIPCHK(hipMalloc(&c->d_payload[i], (size_t)o.payload_len));
       HIPCHK(hipMemcpy(c->d_payload[i], (const char*)blob + o.payload_off, (size_t)o.payload_len, hipMemcpyHostToDevice));
     }
   }
-  *out = c;
+  *out = c.release();
   return 0;
 }
-extern "C" int dctfhe_circuit_destroy(dctfhe_circuit* c) {
-  if (!c) return 0;
-  hipSetDevice(c->ctx->device);
-  for (void* p : c->d_payload) if (p) hipFree(p);
-  delete c;
-  return 0;
-}
+extern "C" int dctfhe_circuit_destroy(dctfhe_circuit* c) { delete c; return 0; }
 extern "C" int dctfhe_circuit_io(dctfhe_circuit* c, int64_t* n_in, int64_t* n_out) {
   const TensorShape& a = c->tensors[c->input_tensor];
   const TensorShape& b = c->tensors[c->output_tensor];
@@ -771,7 +1051,7 @@ extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, d
 extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_keys* keys, int batch, dctfhe_session** out) {
   if (batch < 1) return fail("batch must be >= 1");
   HIPCHK(hipSetDevice(ctx->device));
-  auto* s = new dctfhe_session;
+  std::unique_ptr<dctfhe_session> s(new dctfhe_session);
   s->ctx = ctx; s->circ = circ; s->keys = keys; s->batch = batch;
   s->D = keys ? keys->p.D : 0;
   const size_t L = (size_t)s->D + 1;
@@ -781,9 +1061,9 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
       const Op& o = circ->ops[i];
       if (o.type != OP_LUT) continue;
       const int tt = o.ip[4], bt = o.ip[5], r = o.ip[9] ? 0 : o.ip[1], w = o.ip[2];
-      if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) { delete s; return fail("op %zu names a tier the keys lack", i); }
-      if (w > keys->p.tiers[tt].logN - 1) { delete s; return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt); }
-      if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) { delete s; return fail("op %zu names a coarse bit tier the keys lack", i); }
+      if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) return fail("op %zu names a tier the keys lack", i);
+      if (w > keys->p.tiers[tt].logN - 1) return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt);
+      if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) return fail("op %zu names a coarse bit tier the keys lack", i);
     }
   // tensor liveness: free a buffer after its last reader; reuse freed buffers of sufficient size
   const int nt = (int)circ->tensors.size();
@@ -794,6 +1074,8 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
     if (o.type == OP_ADD) last_use[o.src1] = i;
   }
   last_use[circ->output_tensor] = 1 << 30;
+  // the input stays resident too: dctfhe_session_run may be called again without a fresh upload (bench.py does)
+  last_use[circ->input_tensor] = 1 << 30;
   s->d_tensor.assign(nt, nullptr);
   s->tensor_words.assign(nt, 0);
   for (int t = 0; t < nt; t++) {
@@ -819,10 +1101,10 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
     if (!cap.count(p)) cap[p] = s->tensor_words[t];
     return 0;
   };
-  if (alloc_t(circ->input_tensor)) { delete s; return -1; }
+  CHK(alloc_t(circ->input_tensor));
   for (int i = 0; i < (int)circ->ops.size(); i++) {
     const Op& o = circ->ops[i];
-    if (alloc_t(o.dst)) { delete s; return -1; }
+    CHK(alloc_t(o.dst));
     auto release = [&](int t) {
       if (last_use[t] == i && t != o.dst && s->d_tensor[t]) freelist.push_back({cap[s->d_tensor[t]], s->d_tensor[t]});
     };
@@ -833,24 +1115,23 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
     size_t maxe = 1;
     for (const Op& o : circ->ops)
       if (o.type == OP_LUT) { const TensorShape& x = circ->tensors[o.src0]; maxe = std::max(maxe, (size_t)batch * x.C * x.H * x.W); }
-    LutScratch sc;
-    if (alloc_lut_scratch(keys, std::min<size_t>(maxe, 16384), &sc)) { delete s; return -1; }
-    s->chunk = sc.chunk; s->d_digits = sc.digits; s->d_bodies = sc.bodies; s->d_small = sc.small; s->d_bit_tables = sc.bit_tables;
+    LutScratchOwner sc;
+    CHK(alloc_lut_scratch(keys, std::min<size_t>(maxe, 16384), &sc.s));
+    s->chunk = sc.s.chunk; s->d_digits = sc.s.digits; s->d_bodies = sc.s.bodies; s->d_small = sc.s.small; s->d_bit_tables = sc.s.bit_tables;
+    sc.s = LutScratch{};      // the session owns them now
   }
   HIPCHK(hipMalloc(&s->d_overflow, sizeof(int)));
   HIPCHK(hipMemset(s->d_overflow, 0, sizeof(int)));
-  *out = s;
+  if (keys) {
+    dctfhe_stats stt;
+    dctfhe_circuit_stats(circ, &keys->p, &stt);
+    for (int i = 0; i < DCTFHE_MAX_TIERS; i++) s->pbs_per_image[i] = stt.pbs_count[i];
+  }
+  *out = s.release();
   return 0;
 }
 
-extern "C" int dctfhe_session_destroy(dctfhe_session* s) {
-  if (!s) return 0;
-  hipSetDevice(s->ctx->device);
-  for (auto& o : s->owned) hipFree(o.second);
-  hipFree(s->d_digits); hipFree(s->d_bodies); hipFree(s->d_small); hipFree(s->d_bit_tables); hipFree(s->d_overflow);
-  delete s;
-  return 0;
-}
+extern "C" int dctfhe_session_destroy(dctfhe_session* s) { delete s; return 0; }
 
 extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) {
   HIPCHK(hipSetDevice(s->ctx->device));
@@ -900,10 +1181,8 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
   dctfhe_keys* K = s->keys;
   const size_t L = (size_t)s->D + 1;
   const int B = s->batch;
-  Timers tm{st, timing != nullptr, {}};
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  Timers tm{st, timing != nullptr, &s->ev_pool, {}};
+  const hipEvent_t e0 = tm.take(), e1 = tm.take();
   HIPCHK(hipEventRecord(e0, st));
   if (timing) memset(timing, 0, sizeof *timing);
   LutScratch sc{s->d_digits, s->d_bodies, s->d_small, s->d_bit_tables, s->chunk};
@@ -943,7 +1222,8 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
         if (!K) {
           const double sg = i < s->sim_sigma.size() ? s->sim_sigma[i] : 0.0;
           hipLaunchKernelGGL(k_lut_clear, dim3(ew_grid(E)), dim3(256), 0, st, src, dst, E, shift, body_add, p, r, w, (const int64_t*)c->d_payload[i],
-                             hw, nchan, s->d_overflow, sg, s->sim_seed, (uint64_t)(0x51D0000 + (s->sim_run << 12) + i), (int)(o.ip[9] != 0));
+                             hw, nchan, s->d_overflow, sg, rng_key{{(uint32_t)s->sim_seed, (uint32_t)(s->sim_seed >> 32), 0x73696d75u, 0, 0, 0, 0, 0}},
+                             (uint64_t)(0x51D0000 + (s->sim_run << 12) + i), (int)(o.ip[9] != 0));
           HIPCHK(hipGetLastError());
         } else {
           const int h = tm.begin(CAT_LINEAR);
@@ -976,15 +1256,9 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
       if (sp.cat == CAT_LINEAR) timing->linear_ms += t;
       else if (sp.cat == CAT_KS) timing->ks_ms += t;
       else if (sp.cat >= 0 && sp.cat < DCTFHE_MAX_TIERS) { timing->pbs_ms[sp.cat] += t; timing->pbs_launches[sp.cat]++; }
-      hipEventDestroy(sp.a); hipEventDestroy(sp.b);
     }
-    if (K) {
-      dctfhe_stats stt;
-      dctfhe_circuit_stats(c, &K->p, &stt);
-      for (int i = 0; i < DCTFHE_MAX_TIERS; i++) timing->pbs_cts[i] = stt.pbs_count[i] * B;
-    }
+    for (int i = 0; i < DCTFHE_MAX_TIERS; i++) timing->pbs_cts[i] = s->pbs_per_image[i] * B;
   }
-  hipEventDestroy(e0); hipEventDestroy(e1);
   if (!K) {
     int ov = 0;
     HIPCHK(hipMemcpy(&ov, s->d_overflow, sizeof ov, hipMemcpyDeviceToHost));

@@ -11,29 +11,62 @@
 namespace dctfhe {
 
 // ------------------------------------------------------------------------------------------ rng
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
+// Counter-based CSPRNG: ChaCha20 (D. J. Bernstein's layout: 256-bit key, 64-bit block counter, 64-bit stream id), one 64-byte
+// block = eight u64 outputs; (key, stream, index) -> 64 bits, any index in any order, so every kernel draws exactly the
+// values keygen drew (the test views regenerate keys from the client handle).  Two keys per client: the SECRET key feeds the
+// secret-key bits and every noise term; the PUBLIC key (one ChaCha block of the secret one) feeds the ciphertext / key masks.
+// The reference's runtime (Concrete) seeds an AES-CTR generator the same way.
+struct rng_key { uint32_t k[8]; };
+
+#define DCTFHE_QR(a, b, c, d)                                   \
+  a += b; d ^= a; d = (d << 16) | (d >> 16);                    \
+  c += d; b ^= c; b = (b << 12) | (b >> 20);                    \
+  a += b; d ^= a; d = (d << 8) | (d >> 24);                     \
+  c += d; b ^= c; b = (b << 7) | (b >> 25);
+
+// one ChaCha20 block; out[16] little-endian words
+__host__ __device__ inline void chacha20_block(const rng_key& key, uint64_t stream, uint64_t block, uint32_t* out) {
+  const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                           key.k[4], key.k[5], key.k[6], key.k[7], (uint32_t)block, (uint32_t)(block >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7], x8 = in[8], x9 = in[9],
+           x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    DCTFHE_QR(x0, x4, x8, x12) DCTFHE_QR(x1, x5, x9, x13) DCTFHE_QR(x2, x6, x10, x14) DCTFHE_QR(x3, x7, x11, x15)
+    DCTFHE_QR(x0, x5, x10, x15) DCTFHE_QR(x1, x6, x11, x12) DCTFHE_QR(x2, x7, x8, x13) DCTFHE_QR(x3, x4, x9, x14)
+  }
+  out[0] = x0 + in[0]; out[1] = x1 + in[1]; out[2] = x2 + in[2]; out[3] = x3 + in[3]; out[4] = x4 + in[4]; out[5] = x5 + in[5];
+  out[6] = x6 + in[6]; out[7] = x7 + in[7]; out[8] = x8 + in[8]; out[9] = x9 + in[9]; out[10] = x10 + in[10]; out[11] = x11 + in[11];
+  out[12] = x12 + in[12]; out[13] = x13 + in[13]; out[14] = x14 + in[14]; out[15] = x15 + in[15];
 }
-// counter-based: (seed, stream, index) -> 64 uniform bits
-__device__ __forceinline__ uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t idx) {
-  return mix64(mix64(seed ^ (stream * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)) + idx * 0xD1B54A32D192ED03ULL);
+// (key, stream, index) -> 64 uniform bits: word pair (index & 7) of block (index >> 3)
+__host__ __device__ inline uint64_t rnd64(const rng_key& key, uint64_t stream, uint64_t idx) {
+  uint32_t o[16];
+  chacha20_block(key, stream, idx >> 3, o);
+  uint64_t v = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++)
+    if ((int)(idx & 7) == w) v = (uint64_t)o[2 * w] | ((uint64_t)o[2 * w + 1] << 32);
+  return v;
 }
-__device__ __forceinline__ int64_t gauss_torus(uint64_t seed, uint64_t stream, uint64_t idx, double sigma) {
+__device__ __forceinline__ int64_t gauss_torus(const rng_key& key, uint64_t stream, uint64_t idx, double sigma) {
   if (sigma <= 0.0) return 0;
-  const double u1 = ((double)(rnd64(seed, stream, 2 * idx) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
-  const double u2 = ((double)(rnd64(seed, stream, 2 * idx + 1) >> 11)) * (1.0 / 9007199254740992.0);
+  const double u1 = ((double)(rnd64(key, stream, 2 * idx) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(rnd64(key, stream, 2 * idx + 1) >> 11)) * (1.0 / 9007199254740992.0);
   const double g = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
   return (int64_t)rint(g * sigma * 18446744073709551616.0);
 }
 
-enum : uint64_t { STREAM_BIGKEY = 1, STREAM_SMALLKEY = 2, STREAM_KSK = 16, STREAM_BSK_MASK = 64, STREAM_BSK_NOISE = 128,
-                  STREAM_ENC = 256 };
+// stream ids.  Masks are drawn from the PUBLIC key at stream s, the matching noise from the SECRET key at stream s + 1.
+enum : uint64_t { STREAM_BIGKEY = 1, STREAM_SMALLKEY = 2, STREAM_PUBKEY = 3, STREAM_KSK = 16, STREAM_BSK_MASK = 64, STREAM_ENC = 256 };
 
-__global__ void k_gen_bits(uint64_t seed, uint64_t stream, uint8_t* out, int len) {
+__global__ void k_gen_bits(rng_key key, uint64_t stream, uint8_t* out, int len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < len) out[i] = (uint8_t)(rnd64(seed, stream, (uint64_t)i) >> 63);
+  if (i < len) out[i] = (uint8_t)(rnd64(key, stream, (uint64_t)i) >> 63);
+}
+__global__ void k_rng_fill(rng_key key, uint64_t stream, uint64_t idx0, uint64_t* out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = rnd64(key, stream, idx0 + i);
 }
 
 __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t* red) {
@@ -49,18 +82,18 @@ __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t* red) 
 // ------------------------------------------------------------------------------------------ client
 // one block per ciphertext: a random on [0,dim_eff), b = <a,S> + phase + e
 __global__ void k_lwe_encrypt(const uint8_t* __restrict__ S, int D, int dim_eff, const uint64_t* __restrict__ phases,
-                              double sigma, uint64_t seed, uint64_t* __restrict__ cts) {
+                              double sigma, rng_key pub, rng_key sec, uint64_t stream, uint64_t* __restrict__ cts) {
   __shared__ uint64_t red[16];
   const size_t c = blockIdx.x;
   uint64_t* ct = cts + c * (size_t)(D + 1);
   uint64_t part = 0;
   for (int j = threadIdx.x; j < D; j += blockDim.x) {
-    const uint64_t a = (j < dim_eff) ? rnd64(seed, STREAM_ENC, c * (uint64_t)(D + 1) + j) : 0;
+    const uint64_t a = (j < dim_eff) ? rnd64(pub, stream, c * (uint64_t)(D + 1) + j) : 0;
     ct[j] = a;
     if (S[j]) part += a;
   }
   const uint64_t s = block_reduce_add(part, red);
-  if (threadIdx.x == 0) ct[D] = s + phases[c] + (uint64_t)gauss_torus(seed, STREAM_ENC + 1, c, sigma);
+  if (threadIdx.x == 0) ct[D] = s + phases[c] + (uint64_t)gauss_torus(sec, stream + 1, c, sigma);
 }
 
 __global__ void k_lwe_phase(const uint8_t* __restrict__ S, int D, const uint64_t* __restrict__ cts, uint64_t* __restrict__ phases) {
@@ -77,20 +110,20 @@ __global__ void k_lwe_phase(const uint8_t* __restrict__ S, int D, const uint64_t
 // ------------------------------------------------------------------------------------------ keygen
 // key-switch key: one block per row (i, lev): LWE_s(S_i * 2^(64 - betak (lev+1)))
 __global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restrict__ s, int n, int lk, int betak,
-                          double sigma, uint64_t seed, uint64_t stream, uint64_t* __restrict__ ksk) {
+                          double sigma, rng_key pub, rng_key sec, uint64_t stream, uint64_t* __restrict__ ksk) {
   __shared__ uint64_t red[16];
   const size_t row = blockIdx.x;
   const int i = (int)(row / lk), lev = (int)(row % lk);
   uint64_t* dst = ksk + row * (size_t)(n + 1);
   uint64_t part = 0;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const uint64_t a = rnd64(seed, stream, row * (uint64_t)(n + 1) + j);
+    const uint64_t a = rnd64(pub, stream, row * (uint64_t)(n + 1) + j);
     dst[j] = a;
     if (s[j]) part += a;
   }
   const uint64_t sum = block_reduce_add(part, red);
   if (threadIdx.x == 0) {
-    uint64_t b = sum + (uint64_t)gauss_torus(seed, stream + 1, row, sigma);
+    uint64_t b = sum + (uint64_t)gauss_torus(sec, stream + 1, row, sigma);
     if (S[i]) b += 1ULL << (64 - betak * (lev + 1));
     dst[n] = b;
   }
@@ -107,7 +140,7 @@ __global__ void k_pair_secret(const uint8_t* __restrict__ s, int n, uint8_t* __r
 // bootstrap key, standard domain, rows [i0, i0+ni) x rows_per_bit: GLWE(0) + s_i * gadget.
 // One block per row; the mask polynomial is parked in LDS while the body accumulates A * S.
 __global__ void k_bsk_gen_std(const uint8_t* __restrict__ s_small, const uint8_t* __restrict__ S_glwe, int i0, int k, int N, int l,
-                              int beta, double sigma, uint64_t seed, uint64_t stream, uint64_t* __restrict__ out) {
+                              int beta, double sigma, rng_key pub, rng_key sec, uint64_t stream, uint64_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* A = reinterpret_cast<uint64_t*>(smem_raw);
   const int rows = (k + 1) * l;
@@ -116,11 +149,11 @@ __global__ void k_bsk_gen_std(const uint8_t* __restrict__ s_small, const uint8_t
   uint64_t* row = out + (size_t)blockIdx.x * (k + 1) * N;
   uint64_t* B = row + (size_t)k * N;
   for (int c = threadIdx.x; c < N; c += blockDim.x)
-    B[c] = (uint64_t)gauss_torus(seed, stream + 1, grow * (uint64_t)N + c, sigma);
+    B[c] = (uint64_t)gauss_torus(sec, stream + 1, grow * (uint64_t)N + c, sigma);
   for (int j = 0; j < k; j++) {
     __syncthreads();
     for (int c = threadIdx.x; c < N; c += blockDim.x) {
-      const uint64_t a = rnd64(seed, stream, (grow * (uint64_t)k + j) * (uint64_t)N + c);
+      const uint64_t a = rnd64(pub, stream, (grow * (uint64_t)k + j) * (uint64_t)N + c);
       A[c] = a;
       row[(size_t)j * N + c] = a;
     }
@@ -504,7 +537,7 @@ __global__ void k_sum_pool(const uint64_t* __restrict__ in, int C, int H, int W,
 // rotation of the test vector does the rest.
 __global__ void k_lut_clear(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t count, int shift, uint64_t body_add,
                             int p, int r, int w, const int64_t* __restrict__ tables, int hw, int nchan, int* __restrict__ overflow,
-                            double sigma, uint64_t seed, uint64_t stream, int approx) {
+                            double sigma, rng_key seed, uint64_t stream, int approx) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
     uint64_t v = (in[e] << shift) + body_add;
     if (r > 0 && !(approx && sigma > 0)) v += 1ULL << (63 - p + r - 1);

@@ -221,17 +221,24 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
   const int msh = 64 - LOGN - 2;
   const cplx twist = A.twist[t];
 
-  // L2 warm-up geometry: this workgroup owns lines [pf_line0, pf_line0 + pf_per) of every key bit
+  // L2 warm-up geometry: this workgroup owns lines [pf_line0, pf_line0 + pf_per) of every key bit.
+  // CONTRACT (checked by launch_pbs on the host, asserted by tests/emul for every shipped geometry): iteration i touches
+  // bytes of iteration i + PBS_PF_DIST of the key, so the key buffer carries PBS_PF_DIST iterations (KEY_BLOCKS blocks
+  // each) of padding at its end; pf_parts is 0 (every thread re-touches line 0 of its iteration: no warm-up) or >= 8.
+  // With bsk_wrap > 0 (cache experiments: the key buffer only holds bsk_wrap blocks) the pointer does not advance and
+  // stays on block 0 -- it used to walk n iterations into a buffer of bsk_wrap blocks (the memory access fault recorded
+  // in profiles/r01_exp_two_bit_rotation.log: a wrap case of the tools/exp_pbs.hip sweep with the warm-up on).
   constexpr int PF_LINES = (int)(G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT * 16 / 128);
   constexpr int PF_ROUNDS = (PF_LINES / 8 + T - 1) / T;      // touches per thread per iteration; covers pf_parts >= 8
   const char* pf_ptr;
+  const size_t pf_step = A.bsk_wrap > 0 ? 0 : (size_t)G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT * 16;     // loop-invariant, wave-uniform
   {
     const int parts = A.pf_parts >= 8 ? A.pf_parts : PF_LINES;                 // pf_parts == 0: every thread re-touches line 0
     const int per = (PF_LINES + parts - 1) / parts;
     int line = A.pf_rank * per + (t < per ? t : per - 1);
     if (line > PF_LINES - 1 - (PF_ROUNDS - 1) * T) line = PF_LINES - 1 - (PF_ROUNDS - 1) * T;
     if (line < 0) line = 0;
-    pf_ptr = reinterpret_cast<const char*>(A.bsk + (size_t)PBS_PF_DIST * G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT) + (size_t)line * 128;
+    pf_ptr = reinterpret_cast<const char*>(A.bsk) + (size_t)PBS_PF_DIST * pf_step + (size_t)line * 128;
   }
   acc_t acc[K + 1][2 * P];
   {  // ACC = X^{-b~} * TV (trivial GLWE)
@@ -531,7 +538,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #else
       pf_dump[t] = acc_pf;
 #endif
-      pf_ptr += G::KEY_BLOCKS * G::BSK_ELEMS_PER_KEYBIT * 16;
+      pf_ptr += pf_step;
     }
 
     if constexpr (G::PAIR) fft_inverse_n<G::LOGM, P, 2>(out, t, tw, twist, exch, sync, wsync);

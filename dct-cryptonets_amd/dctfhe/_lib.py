@@ -40,9 +40,10 @@ class Timing(C.Structure):
 
 EXPORTS = [
     "dctfhe_last_error", "dctfhe_version", "dctfhe_ctx_create", "dctfhe_ctx_destroy", "dctfhe_ctx_set_stream",
-    "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_keys_destroy", "dctfhe_keys_export_secret",
-    "dctfhe_keys_export_ksk", "dctfhe_keys_export_bsk", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
-    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_circuit_load", "dctfhe_circuit_destroy",
+    "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_client_key_create", "dctfhe_client_key_destroy", "dctfhe_eval_keys_generate",
+    "dctfhe_eval_keys_destroy", "dctfhe_eval_keys_export", "dctfhe_eval_keys_import", "dctfhe_client_key_export_secret",
+    "dctfhe_eval_keys_export_ksk", "dctfhe_client_key_export_bsk", "dctfhe_rng_host", "dctfhe_rng_device", "dctfhe_client_key_set_encrypt_counter", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
+    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_circuit_load", "dctfhe_circuit_destroy", "dctfhe_params_check", "dctfhe_circuit_validate",
     "dctfhe_circuit_stats", "dctfhe_circuit_io", "dctfhe_session_create", "dctfhe_session_destroy",
     "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
 ]
@@ -69,12 +70,20 @@ def load():
     L.dctfhe_ctx_destroy.argtypes = [vp]
     L.dctfhe_ctx_set_stream.argtypes = [vp, vp]
     L.dctfhe_ctx_synchronize.argtypes = [vp]
-    L.dctfhe_keygen.argtypes = [vp, C.POINTER(Params), u64, C.POINTER(vp)]
-    L.dctfhe_keys_destroy.argtypes = [vp]
-    L.dctfhe_keys_export_secret.argtypes = [vp, vp, vp]
-    L.dctfhe_keys_export_ksk.argtypes = [vp, i32, vp]
-    L.dctfhe_keys_export_bsk.argtypes = [vp, i32, vp]
-    L.dctfhe_encrypt.argtypes = [vp, vp, vp, sz, u64, vp]
+    L.dctfhe_keygen.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(vp), C.POINTER(vp)]
+    L.dctfhe_client_key_create.argtypes = [vp, C.POINTER(Params), C.c_char_p, C.POINTER(vp)]
+    L.dctfhe_client_key_destroy.argtypes = [vp]
+    L.dctfhe_eval_keys_generate.argtypes = [vp, C.POINTER(vp)]
+    L.dctfhe_eval_keys_destroy.argtypes = [vp]
+    L.dctfhe_eval_keys_export.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.dctfhe_eval_keys_import.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.dctfhe_client_key_export_secret.argtypes = [vp, vp, vp]
+    L.dctfhe_eval_keys_export_ksk.argtypes = [vp, i32, vp]
+    L.dctfhe_client_key_export_bsk.argtypes = [vp, i32, vp]
+    L.dctfhe_rng_host.argtypes = [C.c_char_p, u64, u64, sz, vp]
+    L.dctfhe_rng_device.argtypes = [vp, C.c_char_p, u64, u64, sz, vp]
+    L.dctfhe_client_key_set_encrypt_counter.argtypes = [vp, u64]
+    L.dctfhe_encrypt.argtypes = [vp, vp, vp, sz, vp]
     L.dctfhe_decrypt.argtypes = [vp, vp, vp, sz, vp]
     L.dctfhe_keyswitch.argtypes = [vp, vp, i32, vp, sz, i32, vp]
     L.dctfhe_session_set_noise.argtypes = [vp, C.c_uint64, vp, i32]
@@ -82,6 +91,8 @@ def load():
     L.dctfhe_pbs.argtypes = [vp, vp, i32, vp, sz, vp, i32, i32, vp, vp]
     L.dctfhe_round_lut.argtypes = [vp, vp, i32, i32, vp, sz, i32, i32, vp, i32, i32, vp, vp]
     L.dctfhe_conv2d.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    L.dctfhe_params_check.argtypes = [C.POINTER(Params)]
+    L.dctfhe_circuit_validate.argtypes = [vp, sz]
     L.dctfhe_circuit_load.argtypes = [vp, vp, sz, C.POINTER(vp)]
     L.dctfhe_circuit_destroy.argtypes = [vp]
     L.dctfhe_circuit_stats.argtypes = [vp, C.POINTER(Params), C.POINTER(Stats)]

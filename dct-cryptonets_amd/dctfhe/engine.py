@@ -1,5 +1,7 @@
 """Object layer over the C ABI: Context, Keys, Circuit, Session (host numpy buffers in and out)."""
 import ctypes as C
+import hashlib
+import os
 
 import numpy as np
 
@@ -49,11 +51,27 @@ class Context:
             self.h = C.c_void_p()
 
 
-class Keys:
-    def __init__(self, ctx, params, seed):
+def seed_bytes(seed=None):
+    """The 32-byte CSPRNG seed of a client key.  None: fresh from the OS (os.urandom) -- the default everywhere;
+    32 bytes: used as they are (a persisted or broadcast key); int: a DETERMINISTIC seed for tests and reproducible
+    experiments (SHA-256 of a label and the integer) -- guessable by construction, never for real data."""
+    if seed is None:
+        return os.urandom(32)
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32:
+            raise ValueError("a key seed is exactly 32 bytes")
+        return bytes(seed)
+    return hashlib.sha256(b"dctfhe deterministic test seed " + str(int(seed)).encode()).digest()
+
+
+class ClientKey:
+    """Secret side (include/dctfhe.h dctfhe_client_key): encrypts, decrypts, generates evaluation keys."""
+
+    def __init__(self, ctx, params, seed=None):
         self.ctx, self.params, self.L = ctx, params, ctx.L
+        self.seed = seed_bytes(seed)
         self.h = C.c_void_p()
-        check(self.L.dctfhe_keygen(ctx.h, C.byref(params), seed, C.byref(self.h)))
+        check(self.L.dctfhe_client_key_create(ctx.h, C.byref(params), self.seed, C.byref(self.h)))
 
     @property
     def D(self):
@@ -62,35 +80,79 @@ class Keys:
     def tier(self, i):
         return self.params.tiers[i]
 
+    def generate_eval_keys(self):
+        h = C.c_void_p()
+        check(self.L.dctfhe_eval_keys_generate(self.h, C.byref(h)))
+        return EvalKeys(self.ctx, self.params, h)
+
     def export_secret(self):
         S = np.empty(self.params.D, np.uint8)
         s = np.empty(self.params.n_max, np.uint8)
-        check(self.L.dctfhe_keys_export_secret(self.h, ptr(S), ptr(s)))
+        check(self.L.dctfhe_client_key_export_secret(self.h, ptr(S), ptr(s)))
         return S, s
-
-    def export_ksk(self, tier):
-        t = self.tier(tier)
-        out = np.empty((self.params.D, t.lk, t.n + 1), np.uint64)
-        check(self.L.dctfhe_keys_export_ksk(self.h, tier, ptr(out)))
-        return out
 
     def export_bsk(self, tier):
         t = self.tier(tier)
         blocks = 3 * t.n // 2 if t.unroll == 2 else t.n        # unroll 2: the key of the pair secret
         out = np.empty((blocks, (t.k + 1) * t.l, t.k + 1, 1 << t.logN), np.uint64)
-        check(self.L.dctfhe_keys_export_bsk(self.h, tier, ptr(out)))
+        check(self.L.dctfhe_client_key_export_bsk(self.h, tier, ptr(out)))
         return out
 
-    def encrypt(self, phases, seed):
+    def set_encrypt_counter(self, next_call):
+        """processes that share this key (ranks of one job) take disjoint ranges, e.g. rank << 32"""
+        check(self.L.dctfhe_client_key_set_encrypt_counter(self.h, next_call))
+
+    def encrypt(self, phases):
         phases = np.ascontiguousarray(phases, np.uint64).reshape(-1)
         out = np.empty((phases.size, self.D + 1), np.uint64)
-        check(self.L.dctfhe_encrypt(self.ctx.h, self.h, ptr(phases), phases.size, seed, ptr(out)))
+        check(self.L.dctfhe_encrypt(self.ctx.h, self.h, ptr(phases), phases.size, ptr(out)))
         return out
 
     def decrypt(self, cts):
         cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, self.D + 1)
         out = np.empty(cts.shape[0], np.uint64)
         check(self.L.dctfhe_decrypt(self.ctx.h, self.h, ptr(cts), cts.shape[0], ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.dctfhe_client_key_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class EvalKeys:
+    """Server side (dctfhe_eval_keys): key-switch keys + Fourier bootstrap keys; all the evaluation needs."""
+
+    def __init__(self, ctx, params, handle):
+        self.ctx, self.params, self.L, self.h = ctx, params, ctx.L, handle
+
+    @classmethod
+    def from_blob(cls, ctx, blob):
+        """evaluation keys as shipped by a client (EvalKeys.to_blob): the server never sees a secret"""
+        blob = np.ascontiguousarray(np.frombuffer(blob, np.uint8) if isinstance(blob, (bytes, bytearray, memoryview)) else blob, np.uint8)
+        h = C.c_void_p()
+        check(ctx.L.dctfhe_eval_keys_import(ctx.h, ptr(blob), blob.size, C.byref(h)))
+        params = Params.from_buffer_copy(blob[16:16 + C.sizeof(Params)].tobytes())       # header: magic, version, total_bytes, params
+        return cls(ctx, params, h)
+
+    def to_blob(self):
+        n = C.c_size_t()
+        check(self.L.dctfhe_eval_keys_export(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint8)
+        check(self.L.dctfhe_eval_keys_export(self.h, ptr(out), out.size, C.byref(n)))
+        return out
+
+    @property
+    def D(self):
+        return self.params.D
+
+    def tier(self, i):
+        return self.params.tiers[i]
+
+    def export_ksk(self, tier):
+        t = self.tier(tier)
+        out = np.empty((self.params.D, t.lk, t.n + 1), np.uint64)
+        check(self.L.dctfhe_eval_keys_export_ksk(self.h, tier, ptr(out)))
         return out
 
     def keyswitch(self, tier, cts, shift=0, deff=0):
@@ -125,8 +187,36 @@ class Keys:
 
     def close(self):
         if self.h:
-            self.L.dctfhe_keys_destroy(self.h)
+            self.L.dctfhe_eval_keys_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class Keys:
+    """Both halves in one process (tests, benchmarks, the reference's single-machine flow homomorphic_eval.py:313-317):
+    `.client` (ClientKey) and `.eval` (EvalKeys); every method is the half's own."""
+
+    def __init__(self, ctx, params, seed=None, client=None, evalk=None):
+        self.ctx, self.params = ctx, params
+        self.client = client if client is not None else ClientKey(ctx, params, seed)
+        self.eval = evalk if evalk is not None else self.client.generate_eval_keys()
+
+    @property
+    def D(self):
+        return self.params.D
+
+    def tier(self, i):
+        return self.params.tiers[i]
+
+    def __getattr__(self, name):
+        if name in ("export_secret", "export_bsk", "encrypt", "decrypt", "seed"):
+            return getattr(self.client, name)
+        if name in ("export_ksk", "keyswitch", "pbs", "round_lut", "bench_pbs", "to_blob"):
+            return getattr(self.eval, name)
+        raise AttributeError(name)
+
+    def close(self):
+        self.eval.close()
+        self.client.close()
 
 
 class Circuit:
@@ -154,6 +244,8 @@ class Session:
     """Device tensors for one (circuit, keys, batch).  keys=None: noise-free clear mode (1-word ciphertexts)."""
 
     def __init__(self, ctx, circuit, keys, batch):
+        """keys: EvalKeys (or a Keys pair, whose evaluation half is used) -- a session never needs the secret"""
+        keys = getattr(keys, "eval", keys)
         self.ctx, self.circuit, self.keys, self.batch, self.L = ctx, circuit, keys, batch, ctx.L
         self.words = (keys.D + 1) if keys is not None else 1
         self.h = C.c_void_p()

@@ -47,10 +47,37 @@ class FHECircuit:
     def mlir(self):
         return self._o.compiled.report()
 
-    def keygen(self, seed=1, force=False):
+    def keygen(self, seed=None, force=False):
+        """reference homomorphic_eval.py:315.  seed: None = 32 fresh bytes from the OS (the default); 32 bytes = a persisted /
+        broadcast key seed; int = deterministic test seed (dctfhe.engine.seed_bytes)."""
         self._o._keygen(seed, force)
 
     @property
+    # -- client / server split (reference homomorphic_eval.py:313-317 keeps both halves in one process) ------------
+    def export_evaluation_keys(self):
+        """client side: the evaluation keys as a flat uint8 blob to ship to the server (no secret inside)"""
+        if self._keys is None:
+            self._keygen(None)
+        return self._keys.eval.to_blob()
+
+    def load_evaluation_keys(self, blob):
+        """server side: evaluate with keys a client generated elsewhere; this module can then run `evaluate_encrypted`
+        but can neither encrypt nor decrypt"""
+        from .engine import EvalKeys
+        ctx = self._context()
+        for k in [k for k in self._sessions if k[0] == "execute"]:
+            self._sessions.pop(k).close()
+        if self._keys is not None:
+            self._keys.close()
+        self._keys = EvalKeys.from_blob(ctx, blob)
+
+    def evaluate_encrypted(self, cts, batch):
+        """server side: input ciphertexts [batch * n_in, D+1] -> output ciphertexts [batch * n_out, D+1]"""
+        sess = self._session("execute", batch)
+        sess.upload(cts)
+        sess.run()
+        return sess.download().reshape(-1, self._keys.D + 1)
+
     def statistics(self):
         return self._o.statistics()
 
@@ -67,7 +94,6 @@ class QuantizedModule:
         self.fhe_circuit = FHECircuit(self)
         self.last_timing = None
         self.sim_seed = 977
-        self.enc_seed = 1000
 
     # -- lazy device objects -------------------------------------------------------------
     def _context(self):
@@ -91,9 +117,34 @@ class QuantizedModule:
         if key not in self._sessions:
             ctx = self._context()
             if mode == "execute" and self._keys is None:
-                self._keygen(1)
+                self._keygen(None)
             self._sessions[key] = Session(ctx, self._circuit, self._keys if mode == "execute" else None, batch)
         return self._sessions[key]
+
+    # -- client / server split (reference homomorphic_eval.py:313-317 keeps both halves in one process) ------------
+    def export_evaluation_keys(self):
+        """client side: the evaluation keys as a flat uint8 blob to ship to the server (no secret inside)"""
+        if self._keys is None:
+            self._keygen(None)
+        return self._keys.eval.to_blob()
+
+    def load_evaluation_keys(self, blob):
+        """server side: evaluate with keys a client generated elsewhere; this module can then run `evaluate_encrypted`
+        but can neither encrypt nor decrypt"""
+        from .engine import EvalKeys
+        ctx = self._context()
+        for k in [k for k in self._sessions if k[0] == "execute"]:
+            self._sessions.pop(k).close()
+        if self._keys is not None:
+            self._keys.close()
+        self._keys = EvalKeys.from_blob(ctx, blob)
+
+    def evaluate_encrypted(self, cts, batch):
+        """server side: input ciphertexts [batch * n_in, D+1] -> output ciphertexts [batch * n_out, D+1]"""
+        sess = self._session("execute", batch)
+        sess.upload(cts)
+        sess.run()
+        return sess.download().reshape(-1, self._keys.D + 1)
 
     def statistics(self):
         self._context()
@@ -140,8 +191,7 @@ class QuantizedModule:
                 sess.set_noise(0, None)
         t0 = time.time()
         if mode == "execute":
-            cts = self._keys.encrypt(phases.reshape(-1), self.enc_seed)
-            self.enc_seed += 1
+            cts = self._keys.encrypt(phases.reshape(-1))
             sess.upload(cts)
             timing = sess.run(timing=True)
             out = sess.download().reshape(-1, self._keys.D + 1)

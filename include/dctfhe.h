@@ -31,7 +31,8 @@ extern "C" {
 #define DCTFHE_MAX_TIERS 8
 
 typedef struct dctfhe_ctx dctfhe_ctx;
-typedef struct dctfhe_keys dctfhe_keys;
+typedef struct dctfhe_client_key dctfhe_client_key;   /* CLIENT: secret keys + the CSPRNG keys; never needed by the server */
+typedef struct dctfhe_eval_keys dctfhe_eval_keys;     /* SERVER: key-switch keys + Fourier bootstrap keys (public material) */
 typedef struct dctfhe_circuit dctfhe_circuit;
 typedef struct dctfhe_session dctfhe_session;
 
@@ -89,36 +90,67 @@ int dctfhe_ctx_destroy(dctfhe_ctx* ctx);
 int dctfhe_ctx_set_stream(dctfhe_ctx* ctx, void* hip_stream);
 int dctfhe_ctx_synchronize(dctfhe_ctx* ctx);
 
-/* R3 keygen(): client secret keys + server evaluation keys (KSK, Fourier BSK per tier), on the GPU. */
-int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, uint64_t seed, dctfhe_keys** out);
-int dctfhe_keys_destroy(dctfhe_keys* keys);
-/* client-side view of the keys (tests, and the client that decrypts) */
-int dctfhe_keys_export_secret(dctfhe_keys* keys, uint8_t* big_key /* D */, uint8_t* small_key /* n_max */);
-/* standard-domain evaluation keys (tests): ksk [D][lk][n+1], bsk [n][(k+1)l][k+1][N] */
-int dctfhe_keys_export_ksk(dctfhe_keys* keys, int tier, uint64_t* out);
-int dctfhe_keys_export_bsk(dctfhe_keys* keys, int tier, uint64_t* out);
+/* R3 keygen() (homomorphic_eval.py:313-317).  The reference's `fhe_circuit.keygen()` makes a client key set and the
+ * evaluation keys the server needs; here they are two handles so that the secret never has to reach the server.
+ *
+ * Randomness: a counter-mode ChaCha20 generator on the GPU keyed by the caller's 32-byte seed (draw it from the OS:
+ * os.urandom / getrandom).  The secret-key bits and every noise term come from the seed's own stream; ciphertext and key
+ * MASKS come from a second ChaCha20 key that is one block of the first (public: knowing it gives nothing about the seed).
+ * A client key is a pure function of (params, seed): persist the 32 bytes to persist it; every rank of a multi-GPU job
+ * gets the same keys from the same seed (broadcast the seed, not the keys).
+ * SECURITY STATUS: parameters follow a fit through published 128-bit sets (dctfhe/params.py), not an estimator run --
+ * there is none in this environment; treat the "~128-bit" figure as unverified. */
+int dctfhe_client_key_create(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t seed[32], dctfhe_client_key** out);
+int dctfhe_client_key_destroy(dctfhe_client_key* client);
+/* client side: evaluation keys for `client`'s secret (the expensive part of keygen; runs on the GPU) */
+int dctfhe_eval_keys_generate(dctfhe_client_key* client, dctfhe_eval_keys** out);
+/* both at once */
+int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t seed[32], dctfhe_client_key** client,
+                  dctfhe_eval_keys** eval);
+int dctfhe_eval_keys_destroy(dctfhe_eval_keys* eval);
+/* evaluation-key persistence / shipping to the server: a flat blob (header + parameters, then per tier its key-switch key
+ * and its Fourier bootstrap key).  buf == NULL: only *size is written (size query). */
+int dctfhe_eval_keys_export(dctfhe_eval_keys* eval, void* buf, size_t capacity, size_t* size);
+int dctfhe_eval_keys_import(dctfhe_ctx* ctx, const void* buf, size_t size, dctfhe_eval_keys** out);
 
-/* R4, client half: encrypt phases (already encoded) / return phases b - <a,s>.  Host buffers. */
-int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_keys* keys, const uint64_t* phases, size_t count, uint64_t seed,
+/* test / client views */
+int dctfhe_client_key_export_secret(dctfhe_client_key* client, uint8_t* big_key /* D */, uint8_t* small_key /* n_max */);
+/* standard-domain keys: ksk [D][lk][n+1] (public, from the evaluation keys); bsk [n][(k+1)l][k+1][N], regenerated from the
+ * client's streams -- exactly what dctfhe_eval_keys_generate transformed to the Fourier domain */
+int dctfhe_eval_keys_export_ksk(dctfhe_eval_keys* eval, int tier, uint64_t* out);
+int dctfhe_client_key_export_bsk(dctfhe_client_key* client, int tier, uint64_t* out);
+/* the generator itself: `count` 64-bit outputs (key, stream, idx0 + i).  _host runs on the CPU (known-answer tests need no GPU) */
+int dctfhe_rng_host(const uint8_t key[32], uint64_t stream, uint64_t idx0, size_t count, uint64_t* out);
+int dctfhe_rng_device(dctfhe_ctx* ctx, const uint8_t key[32], uint64_t stream, uint64_t idx0, size_t count, uint64_t* out);
+
+/* R4, client half: encrypt phases (already encoded) / return phases b - <a,s>.  Host buffers.  Every dctfhe_encrypt call
+ * draws masks and noise from fresh generator streams (a per-handle call counter). */
+int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* phases, size_t count,
                    uint64_t* cts /* count x (D+1) */);
-int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_keys* keys, const uint64_t* cts, size_t count, uint64_t* phases);
+/* processes sharing one client key (the ranks of a job) must use disjoint counter ranges, e.g. rank << 32 */
+int dctfhe_client_key_set_encrypt_counter(dctfhe_client_key* client, uint64_t next_call);
+int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* cts, size_t count, uint64_t* phases);
 
 /* R4, server half, one primitive at a time on host buffers (parity tests, integration). */
-int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts, size_t count,
+int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts, size_t count,
                      int shift, uint64_t* cts_small /* count x (n+1) */);
 /* the same when the caller knows every input to be zero beyond mask word `deff` (nested keys: outputs of a ring of
  * dimension k*N <= deff): only the first deff rows of the key are used -- identical result, deff/D of the work */
-int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts, size_t count,
+int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts, size_t count,
                             int shift, int deff, uint64_t* cts_small);
-int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, const uint64_t* cts_small, size_t count,
+int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts_small, size_t count,
                const int64_t* tables /* [ntab][2^w] */, int ntab, int w, const int32_t* table_idx /* may be NULL */,
                uint64_t* cts_out /* count x (D+1) */);
-int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_keys* keys, int bit_tier, int tab_tier, const uint64_t* cts,
+int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int bit_tier, int tab_tier, const uint64_t* cts,
                      size_t count, int p, int r, const int64_t* tables, int ntab, int w,
                      const int32_t* table_idx, uint64_t* cts_out);
 int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int batch, int Cin, int H, int W,
                   const int8_t* weight /* [Cout][Cin][KH][KW] */, int Cout, int KH, int KW, int stride, int pad,
                   uint64_t* out);
+
+/* host-only validators (no GPU): parameter set / circuit blob well-formed?  0 or -1 with dctfhe_last_error() */
+int dctfhe_params_check(const dctfhe_params* params);
+int dctfhe_circuit_validate(const void* blob, size_t size);
 
 /* R1: load a compiled circuit description (built by dctfhe.compile, format in DESIGN.md section 4). */
 int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t size, dctfhe_circuit** out);
@@ -126,11 +158,12 @@ int dctfhe_circuit_destroy(dctfhe_circuit* circ);
 int dctfhe_circuit_stats(dctfhe_circuit* circ, const dctfhe_params* params, dctfhe_stats* out);
 int dctfhe_circuit_io(dctfhe_circuit* circ, int64_t* n_in_per_image, int64_t* n_out_per_image);
 
-/* R4: evaluate the circuit on a batch of images.  A session owns the device tensors. */
-int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_keys* keys /* NULL: clear mode */,
+/* R4: evaluate the circuit on a batch of images.  A session owns the device tensors and needs the EVALUATION keys only. */
+int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_eval_keys* keys /* NULL: clear mode */,
                           int batch, dctfhe_session** out);
 int dctfhe_session_destroy(dctfhe_session* s);
 int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in /* batch x n_in x (D+1); clear: x 1 */);
+/* synchronous.  The uploaded input stays resident: run may be called again without a fresh upload (same result). */
 int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing /* may be NULL */);
 /* clear-mode sessions (keys == NULL) only: `simulate` with the noise model.  sigma_per_op[i] (fraction of the torus, 0 for
  * ops that are not look-ups) is added at the input of op i's table look-up, fresh draws every run; n_ops = 0 switches it off */
@@ -140,7 +173,7 @@ int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out /* batch x n_ou
 /* f64 FMA peak micro-benchmark (TFLOP/s) used to price the blind-rotate kernel in bench.py. */
 int dctfhe_fp64_peak(dctfhe_ctx* ctx, double* tflops);
 /* stand-alone timing of the blind-rotate kernel: count ciphertexts of tier `tier`, average ms per launch */
-int dctfhe_bench_pbs(dctfhe_ctx* ctx, dctfhe_keys* keys, int tier, size_t count, int reps, double* ms_per_launch);
+int dctfhe_bench_pbs(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, size_t count, int reps, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
 
 #include "../../dct-cryptonets_amd/csrc/pbs_core.h"
 #include "../../oracle/tfhe_ref.h"
@@ -234,8 +235,68 @@ template <int LOGN, int P> static int layout_case() {
   return err > 1e-9 || bad != 0;
 }
 
+// The L2 warm-up contract of pbs_core.h, asserted by the MMU: the key buffer holds exactly the key blocks plus PBS_PF_DIST
+// iterations of padding and ends on an inaccessible page, so any touch past the contract faults here, on the host, instead
+// of on a GPU (the recorded fault was a bsk_wrap case: the pointer walked n iterations into a buffer
+// of bsk_wrap blocks).  Values are irrelevant (a zero key); n is small, the geometry is the shipped one.
+template <int LOGN, int K, int L, int P, int MB = 0>
+static int pf_guard_case(int n_in, int wrap, int pf_parts) {
+  using G = pbs_geom<LOGN, K, L, P, MB>;
+  constexpr int N = G::N, T = G::T;
+  const int D = K * N;
+  const size_t blocks = wrap ? (size_t)wrap : (size_t)(MB ? 3 * n_in / 2 : n_in);
+  const size_t bytes = (blocks + (size_t)PBS_PF_DIST * G::KEY_BLOCKS) * G::BSK_ELEMS_PER_KEYBIT * 16;
+  const size_t page = 4096, span = (bytes + page - 1) / page * page;
+  unsigned char* map = (unsigned char*)mmap(nullptr, span + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (map == MAP_FAILED) { std::printf("mmap failed\n"); return 1; }
+  if (mprotect(map + span, page, PROT_NONE)) { std::printf("mprotect failed\n"); return 1; }
+  cplx* bsk_dev = reinterpret_cast<cplx*>(map + (span - bytes));       // the buffer ends exactly where the guard page starts
+  std::vector<cplx> tw(G::F::TW_ELEMS);
+  fill_twiddles<G::LOGM, P>(tw.data());
+  std::vector<cplx> wtab(2 * N + 8, cmk(1.0, 0.0));
+  std::vector<uint64_t> ct(n_in + 1, 0x0123456789abcdefULL), out((size_t)D + 1);
+  std::vector<int64_t> table(16, 1LL << 58);
+  std::vector<unsigned char> shared(G::SHARED_BYTES);
+  std::vector<uint64_t> accl((size_t)G::NL * N + 1);
+  std::vector<uint32_t> pfd(T);
+  const int ranks[2] = {0, pf_parts > 0 ? pf_parts - 1 : 0};
+  for (int pf_rank : ranks) {
+    std::barrier bar(T);
+    auto worker = [&](int t) {
+      auto sync = [&] { bar.arrive_and_wait(); };
+      pbs_args A;
+      A.ct_small = ct.data(); A.n = n_in; A.wtab = wtab.data(); A.beta = L == 1 ? 20 : 10; A.bsk = bsk_dev;
+      A.table = table.data(); A.w = 4; A.out = out.data(); A.D_out = D;
+      A.accumulate = 0; A.body_add = 0; A.bsk_wrap = wrap; A.pf_parts = pf_parts; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = pf_rank;
+      pbs_thread<LOGN, K, L, P, MB>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    for (auto& x : th) x.join();
+  }
+  munmap(map, span + page);
+  std::printf("warm-up range %sN=%d k=%d l=%d n=%d wrap=%d pf_parts=%d: inside the key + %d iterations of padding\n", MB ? "two-bit " : "", N, K, L, n_in, wrap, pf_parts, PBS_PF_DIST);
+  return 0;
+}
+
 int main() {
   int fail = 0;
+  // every geometry the library launches (dctfhe.hip PBS_CASES used by dctfhe/params.py catalogues), pf_parts as launched (16),
+  // the other legal settings, and the cache-experiment switch
+  fail |= pf_guard_case<13, 1, 1, 8, 1>(4, 0, 16);
+  fail |= pf_guard_case<13, 1, 1, 8, 1>(4, 0, 8);
+  fail |= pf_guard_case<13, 1, 1, 8, 1>(4, 0, 32);
+  fail |= pf_guard_case<13, 1, 1, 8, 1>(2, 0, 0);
+  fail |= pf_guard_case<12, 1, 1, 8, 1>(4, 0, 16);
+  fail |= pf_guard_case<11, 1, 1, 8, 1>(4, 0, 16);
+  fail |= pf_guard_case<11, 1, 3, 8>(3, 0, 16);
+  fail |= pf_guard_case<12, 1, 3, 8>(2, 0, 16);
+  fail |= pf_guard_case<13, 1, 3, 8>(2, 0, 16);
+  fail |= pf_guard_case<10, 2, 1, 8>(3, 0, 16);
+  fail |= pf_guard_case<10, 2, 2, 8>(3, 0, 16);
+  fail |= pf_guard_case<12, 1, 2, 8>(2, 0, 16);
+  fail |= pf_guard_case<11, 1, 3, 8>(6, 2, 16);          // bsk_wrap with the warm-up on: the recorded fault's configuration
+  fail |= pf_guard_case<13, 1, 1, 8>(5, 2, 16);
   fail |= torus_case();
   fail |= decompose_case();
   fail |= layout_case<9, 8>();

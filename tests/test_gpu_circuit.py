@@ -53,7 +53,7 @@ def test_session_runs_twice_on_one_upload(tiny):
     q = qm.quantize_input(calib[20:23])
     want = _oracle_out(qm, q)
     sess = qm._session("execute", 3)
-    sess.upload(qm._keys.encrypt(qm.encode_input(q).reshape(-1), 4242))
+    sess.upload(qm._keys.encrypt(qm.encode_input(q).reshape(-1)))
     for _ in range(2):
         sess.run()
         out = sess.download().reshape(-1, qm._keys.D + 1)
@@ -180,7 +180,7 @@ def test_input_on_a_key_prefix_and_tail_guard():
         qm.fhe_circuit.keygen(seed=11)
         q = qm.quantize_input(calib[:3])
         assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
-        cts = qm._keys.encrypt(qm.encode_input(q).reshape(-1), 77).reshape(-1, qm._keys.D + 1)
+        cts = qm._keys.encrypt(qm.encode_input(q).reshape(-1)).reshape(-1, qm._keys.D + 1)
         assert not cts[:, 512:qm._keys.D].any()
         cts[5, 700] = 1
         sess = qm._session("execute", 3)

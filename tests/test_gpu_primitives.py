@@ -33,7 +33,7 @@ def test_encrypt_decrypt_matches_oracle(keys, oracle):
     assert set(np.unique(S)) <= {0, 1} and 0.4 < S.mean() < 0.6
     msgs = np.arange(64, dtype=np.uint64) % 16
     phases = msgs << np.uint64(59)
-    cts = keys.encrypt(phases, seed=3)
+    cts = keys.encrypt(phases)
     # device decrypt == oracle decrypt (integer, bit-exact) and both close to the plaintext phases
     ph_dev = keys.decrypt(cts)
     ph_ref = oracle.lwe_phase(S, D_SMALL, cts)
@@ -45,7 +45,7 @@ def test_keyswitch_bit_exact(keys, oracle):
     S, s = keys.export_secret()
     rng = np.random.default_rng(0)
     phases = rng.integers(0, 16, 50).astype(np.uint64) << np.uint64(59)
-    cts = keys.encrypt(phases, seed=4)
+    cts = keys.encrypt(phases)
     for tier in (0, 1):
         t = TIERS_SMALL[tier]
         ksk = keys.export_ksk(tier)
@@ -150,7 +150,7 @@ def test_round_lut_exact_rounding(keys, oracle):
     S, s = keys.export_secret()
     p, r, w = 7, 3, 4
     msgs = np.arange(0, (1 << p) - (1 << (r - 1)), dtype=np.uint64)      # stay inside the padded range after rounding
-    cts = keys.encrypt(msgs << np.uint64(63 - p), seed=5)
+    cts = keys.encrypt(msgs << np.uint64(63 - p))
     tables = np.stack([(np.arange(16) * 3 + 1) % 16, (15 - np.arange(16))]).astype(np.int64) << 58
     idx = (np.arange(msgs.size) % 2).astype(np.int32)
     out = keys.round_lut(1, 0, cts, p, r, tables, w, idx)
@@ -194,7 +194,25 @@ def test_keyswitch_valu_fallback_bit_exact(gpu_ctx, oracle):
     k = Keys(gpu_ctx, make_params(D, 33, [tier], 2.0 ** -50), seed=9)
     try:
         rng = np.random.default_rng(3)
-        cts = k.encrypt(rng.integers(0, 16, 37).astype(np.uint64) << np.uint64(59), seed=4)
+        cts = k.encrypt(rng.integers(0, 16, 37).astype(np.uint64) << np.uint64(59))
         assert np.array_equal(k.keyswitch(0, cts, shift=2), oracle.keyswitch(cts << np.uint64(2), k.export_ksk(0), 4))
+    finally:
+        k.close()
+
+
+@pytest.mark.parametrize("betak,lk", [(7, 4), (8, 3)])
+def test_keyswitch_widest_gadgets_bit_exact(gpu_ctx, oracle, betak, lk):
+    """the i8 MFMA key switch reads its digit operand as SIGNED bytes, so offset digits in [0, 2^betak) need
+    betak <= 7 (the widest it takes, checked here on a shape the MFMA tiling covers); betak = 8 is accepted by
+    dctfhe_params_check and must go to the integer-VALU GEMM -- bit-exact either way."""
+    from dctfhe.engine import Keys, make_params
+    D = 1024
+    tier = dict(n=40, k=1, logN=10, l=2, beta=10, lk=lk, betak=betak, lwe_sigma=2.0 ** -40, glwe_sigma=2.0 ** -45)
+    k = Keys(gpu_ctx, make_params(D, 40, [tier], 2.0 ** -50), seed=31)
+    try:
+        rng = np.random.default_rng(5)
+        cts = k.encrypt(rng.integers(0, 16, 150).astype(np.uint64) << np.uint64(59))
+        cts[:, :D] |= rng.integers(0, 2 ** 64, (150, D), dtype=np.uint64) & np.uint64(0xFF00000000000000)     # every digit value occurs, the top ones too
+        assert np.array_equal(k.keyswitch(0, cts), oracle.keyswitch(cts, k.export_ksk(0), betak))
     finally:
         k.close()

@@ -10,6 +10,10 @@ using namespace dctfhe;
 template <int LOGN, int K, int L, int P, int GR, int MB = 0>
 void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
+  // every case announces itself BEFORE it launches: a fault then names its case (profiles/r01_exp_two_bit_rotation.log did not)
+  printf("case mb=%d pf=%d wrap=%d N=%d k=%d l=%d P=%d groups=%d n=%d count=%zu ...\n", MB, pf, wrap, 1 << LOGN, K, L, P, GR, n, count);
+  fflush(stdout);
+  if (pf != 0 && pf < 8) { printf("pf_parts must be 0 or >= 8 (kernel contract, pbs_core.h)\n"); return; }
   if (MB && wrap) { printf("wrap is not supported by the two-bit kernels\n"); return; }
   constexpr int N = G::N, M = G::M;
   std::vector<cplx> tw(G::F::TW_ELEMS);

@@ -18,7 +18,7 @@ def main():
     for ti, t in enumerate(ps.tiers):
         w = 4
         msgs = rng.integers(0, 16, count).astype(np.uint64)
-        cts = keys.encrypt(msgs << np.uint64(59), seed=10 + ti)
+        cts = keys.encrypt(msgs << np.uint64(59))
         t0 = time.time()
         small = keys.keyswitch(ti, cts)
         tks = time.time() - t0
