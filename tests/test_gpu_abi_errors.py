@@ -73,7 +73,7 @@ def test_primitive_errors(kit):
     _fails(L, L.dctfhe_conv2d(ctx.h, 4, p(x), 1, 2, 2, 2, p(w), 2, 3, 3, 1, 0, p(x)), "kernel larger")
     _fails(L, L.dctfhe_conv2d(ctx.h, 4, p(x), 1, 2, 2, 2, p(w), 2, 3, 3, 0, 1, p(x)), "bad geometry")
     # the handles still work after all that
-    assert np.array_equal(keys.decrypt(cts) >> np.uint64(57), (np.arange(3, dtype=np.uint64) << np.uint64(1)))
+    assert np.array_equal((keys.decrypt(cts) + np.uint64(1 << 56)) >> np.uint64(57), (np.arange(3, dtype=np.uint64) << np.uint64(1)))
 
 
 def test_circuit_and_session_errors(kit):
