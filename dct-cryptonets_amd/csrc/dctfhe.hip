@@ -899,6 +899,47 @@ extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int bat
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ K10 front-end
+extern "C" int dctfhe_dct_frontend(dctfhe_ctx* ctx, const uint8_t* y, const uint8_t* c1, const uint8_t* c2, int batch, int S, int Sc, int fs,
+                                   const int32_t* idx_y, int ny, const int32_t* idx_c1, int n1, const int32_t* idx_c2, int n2,
+                                   const float* mean, const float* stdv, int round_coeffs, float* out) {
+  if (!ctx || !y || !c1 || !c2 || !mean || !stdv || !out) return fail("dctfhe_dct_frontend: null argument");
+  if (batch < 1 || S < 1 || (Sc != S && 2 * Sc != S) || (fs != 4 && fs != 8)) return fail("dctfhe_dct_frontend: bad geometry (block size 4 or 8; chroma grid S or S/2)");
+  if (ny < 0 || n1 < 0 || n2 < 0 || ny + n1 + n2 < 1) return fail("dctfhe_dct_frontend: no coefficients selected");
+  const int32_t* idx[3] = {idx_y, idx_c1, idx_c2};
+  const int n[3] = {ny, n1, n2};
+  for (int p = 0; p < 3; p++)
+    for (int i = 0; i < n[p]; i++)
+      if (!idx[p] || idx[p][i] < 0 || idx[p][i] >= fs * fs) return fail("dctfhe_dct_frontend: coefficient index out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int C = ny + n1 + n2;
+  const size_t by = (size_t)batch * S * fs * S * fs, bc = (size_t)batch * Sc * fs * Sc * fs, nout = (size_t)batch * C * S * S;
+  DevBuf d_y, d_c1, d_c2, d_idx, d_ms, d_out;
+  HIPCHK(d_y.alloc(by)); HIPCHK(d_c1.alloc(bc)); HIPCHK(d_c2.alloc(bc));
+  HIPCHK(d_idx.alloc((size_t)C * 4)); HIPCHK(d_ms.alloc((size_t)C * 8)); HIPCHK(d_out.alloc(nout * 4));
+  HIPCHK(hipMemcpy(d_y.p, y, by, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_c1.p, c1, bc, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_c2.p, c2, bc, hipMemcpyHostToDevice));
+  dct_args a;
+  a.plane[0] = d_y.as<uint8_t>(); a.plane[1] = d_c1.as<uint8_t>(); a.plane[2] = d_c2.as<uint8_t>();
+  a.S = S; a.Sc = Sc; a.fs = fs; a.round_coeffs = round_coeffs; a.batch = batch;
+  int off = 0;
+  for (int p = 0; p < 3; p++) {
+    a.n[p] = n[p];
+    a.idx[p] = d_idx.as<int32_t>() + off;
+    if (n[p]) HIPCHK(hipMemcpy(d_idx.as<int32_t>() + off, idx[p], (size_t)n[p] * 4, hipMemcpyHostToDevice));
+    off += n[p];
+  }
+  HIPCHK(hipMemcpy(d_ms.p, mean, (size_t)C * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_ms.as<float>() + C, stdv, (size_t)C * 4, hipMemcpyHostToDevice));
+  a.mean = d_ms.as<float>(); a.stdv = d_ms.as<float>() + C; a.out = d_out.as<float>();
+  hipLaunchKernelGGL(k_dct_frontend, dim3(ew_grid(nout)), dim3(256), 0, ctx->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d_out.p, nout * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ circuit
 struct BlobHeader { uint32_t magic, version; int32_t n_tensors, n_ops, input_tensor, output_tensor, max_bit_width, reserved; };
 

@@ -561,6 +561,65 @@ __global__ void k_lut_clear(const uint64_t* __restrict__ in, uint64_t* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------ K10 DCT front-end (client side, plaintext)
+// uint8 planes -> float32 [B][channels][S][S]: (pixel - 128) blockwise orthonormal DCT-II (T B T^t per fs x fs block,
+// reference data/cvfunctional.py:37-57), only the coefficients SubsetDCT keeps (cvtransforms.py:117-142), the two chroma
+// coefficient grids -- DCT'd at half resolution -- bilinearly up-sampled to S x S (UpScaleDCT, cvtransforms.py:56-64;
+// half-pixel centres, edge clamp), channels concatenated Y | slot 1 | slot 2 (Aggregate), then (x - mean) / std in f32
+// (NormalizeDCT, cvtransforms.py:152-208; mean/std already gathered by the caller with the reference's index quirk).
+// One thread per output value; f64 inside like the reference's numpy path.  A few kB per image: nothing to tune.
+struct dct_args {
+  const uint8_t* plane[3];      // Y [B][fs*S][fs*S]; chroma slots [B][fs*Sc][fs*Sc]
+  int S, Sc, fs;                // output grid, chroma grid (S or S/2), block size (4 or 8)
+  int n[3];                     // kept coefficients per plane
+  const int32_t* idx[3];        // their row-major indices u*fs + v
+  const float *mean, *stdv;     // per output channel
+  int round_coeffs;             // JPEG-domain path: coefficients are quantised (round half away from zero) and the up-sampled
+                                // planes rounded half to even, as the int16 arrays of the reference are
+  float* out;                   // [B][n0+n1+n2][S][S]
+  int batch;
+};
+
+__device__ __forceinline__ double dct_basis(int fs, int u, int j) {
+  return u == 0 ? rsqrt((double)fs) : sqrt(2.0 / fs) * cospi((double)((2 * j + 1) * u) / (double)(2 * fs));
+}
+__device__ inline double dct_coeff(const uint8_t* plane, int side, int fs, int by, int bx, int u, int v, int round_coeffs) {
+  double acc = 0.0;
+  for (int i = 0; i < fs; i++) {
+    double row = 0.0;
+    for (int j = 0; j < fs; j++) row += ((double)plane[(size_t)(by * fs + i) * side + bx * fs + j] - 128.0) * dct_basis(fs, v, j);
+    acc += dct_basis(fs, u, i) * row;
+  }
+  if (round_coeffs) acc = copysign(floor(fabs(acc) + 0.5), acc);
+  return acc;
+}
+__global__ void k_dct_frontend(dct_args a) {
+  const int C = a.n[0] + a.n[1] + a.n[2];
+  const size_t total = (size_t)a.batch * C * a.S * a.S;
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(x % a.S), oy = (int)((x / a.S) % a.S), c = (int)((x / ((size_t)a.S * a.S)) % C), b = (int)(x / ((size_t)a.S * a.S * C));
+    const int pl = c < a.n[0] ? 0 : (c < a.n[0] + a.n[1] ? 1 : 2);
+    const int k = a.idx[pl][c - (pl == 0 ? 0 : (pl == 1 ? a.n[0] : a.n[0] + a.n[1]))];
+    const int u = k / a.fs, v = k % a.fs;
+    const int grid = pl == 0 ? a.S : a.Sc, side = grid * a.fs;
+    const uint8_t* plane = a.plane[pl] + (size_t)b * side * side;
+    double val;
+    if (grid == a.S) {
+      val = dct_coeff(plane, side, a.fs, oy, ox, u, v, a.round_coeffs);
+    } else {   // bilinear up-sampling of the coefficient grid
+      const double sy = (oy + 0.5) * ((double)grid / a.S) - 0.5, sx = (ox + 0.5) * ((double)grid / a.S) - 0.5;
+      const int y0 = (int)floor(sy), x0 = (int)floor(sx);
+      const double fy = sy - y0, fx = sx - x0;
+      const int y0c = min(max(y0, 0), grid - 1), y1c = min(max(y0 + 1, 0), grid - 1), x0c = min(max(x0, 0), grid - 1), x1c = min(max(x0 + 1, 0), grid - 1);
+      const double top = dct_coeff(plane, side, a.fs, y0c, x0c, u, v, a.round_coeffs) * (1.0 - fx) + dct_coeff(plane, side, a.fs, y0c, x1c, u, v, a.round_coeffs) * fx;
+      const double bot = dct_coeff(plane, side, a.fs, y1c, x0c, u, v, a.round_coeffs) * (1.0 - fx) + dct_coeff(plane, side, a.fs, y1c, x1c, u, v, a.round_coeffs) * fx;
+      val = top * (1.0 - fy) + bot * fy;
+      if (a.round_coeffs) val = rint(val);
+    }
+    a.out[x] = ((float)val - a.mean[c]) / a.stdv[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ f64 peak probe
 __global__ void k_fp64_peak(double* out, int iters) {
   double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;

@@ -328,9 +328,15 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
     bld = _Builder(ps, rounding_threshold_bits, range_margin)
     sgn_lo, sgn_hi = -(2 ** (bits - 1)), 2 ** (bits - 1) - 1
     uq_hi = 2 ** bits - 1
+    learned = getattr(model, "act_scales", None) or {}
+
+    def scale_of(key, x, signed):
+        """the quantiser's learned scale when the checkpoint carried one (dctfhe.checkpoint), else from the calibration batch"""
+        s = learned.get(key)
+        return float(s) if s else act_scale(x, signed, bits)
 
     # quant_inp (client side, in the clear; reference backbone.py:231,241)
-    s_in = act_scale(calib, True, bits)
+    s_in = scale_of("quant_inp", calib, True)
     q0 = act_quant(calib, s_in, True, bits)
     t_in = bld.tensor(*q0.shape[1:], sgn_lo, sgn_hi)
     a = _Act(q0, s_in, t_in, sgn_lo, sgn_hi)
@@ -341,11 +347,11 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
     _bn_calibrate(model.bn1, real)
     h = _bn_apply(model.bn1, real)
     if model.relu1:
-        s_r = act_scale(np.maximum(h, 0), False, bits)
+        s_r = scale_of("stem_relu", np.maximum(h, 0), False)
         hq = act_quant(np.maximum(h, 0), s_r, False, bits) * s_r
     else:
         s_r, hq = None, h
-    s_q0 = act_scale(hq, True, bits)
+    s_q0 = scale_of("stem_quant_out", hq, True)
 
     def chan_fn(bn, s_acc, post):
         def fn(vals):
@@ -366,7 +372,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
         real1 = acc1.q * acc1.scale
         _bn_calibrate(blk.BN1, real1)
         h1 = np.maximum(_bn_apply(blk.BN1, real1), 0)
-        s_r1 = act_scale(h1, False, bits)
+        s_r1 = scale_of(("block", bi, "relu1"), h1, False)
         r1 = bld.lut_to_conv(acc1, chan_fn(blk.BN1, acc1.scale, lambda x, s=s_r1: act_quant(np.maximum(x, 0), s, False, bits)), True, True, s_r1,
                      f"block{bi}: BN1+relu1")
         # C2 -> BN2 -> quant_out (s4)                                        backbone.py:97-99
@@ -374,7 +380,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
         real2 = acc2.q * acc2.scale
         _bn_calibrate(blk.BN2, real2)
         g2 = _bn_apply(blk.BN2, real2)
-        s_qo = act_scale(g2, True, bits)
+        s_qo = scale_of(("block", bi, "quant_out"), g2, True)
         main_hi, main_lo = sgn_hi * s_qo, sgn_lo * s_qo
         # shortcut                                                           backbone.py:100
         if blk.shortcut is None:
@@ -385,7 +391,7 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
             reals = accs.q * accs.scale
             _bn_calibrate(blk.BNshortcut, reals)
             gs = _bn_apply(blk.BNshortcut, reals)
-            s_qs = act_scale(gs, True, bits)
+            s_qs = scale_of(("block", bi, "BNquant_out"), gs, True)
             sc_lo, sc_hi = sgn_lo * s_qs, sgn_hi * s_qs
         # common integer scale of the residual sum: n_bits signed, guaranteed by construction
         zmax, zmin = 2 ** (n_bits - 1) - 1, -(2 ** (n_bits - 1))
@@ -401,14 +407,14 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
                         True, True, s_c, f"block{bi}: BNshortcut+BNquant_out+rescale")
         z = bld.add(u, v)                                                    # backbone.py:102
         zr = np.maximum(z.q * s_c, 0)
-        s_r2 = act_scale(zr, False, bits)
+        s_r2 = scale_of(("block", bi, "relu2"), zr, False)
         a = bld.lut_to_conv(z, lambda vals, c=s_c, s=s_r2: act_quant(np.maximum(vals * c, 0), s, False, bits), False, False, s_r2, f"block{bi}: relu2")
 
     # AvgPool2d(k) as a window sum, then QuantIdentity (s4)                  backbone.py:276-278
     K = model.avgpool_kernel
     pooled = bld.sum_pool(a, K)
     realp = pooled.q * pooled.scale / (K * K)
-    s_f = act_scale(realp, True, bits)
+    s_f = scale_of("final", realp, True)
     out = bld.lut(pooled, lambda vals, s=pooled.scale / (K * K), f=s_f: act_quant(vals * s, f, True, bits), False, True, s_f, "avgpool+QuantIdentity")
 
     circ = CompiledCircuit(tensors=bld.tensors, ops=bld.ops, input_tensor=t_in, output_tensor=out.tid, in_scale=s_in, in_bits=bits,

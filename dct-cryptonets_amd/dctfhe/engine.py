@@ -36,6 +36,19 @@ class Context:
         check(self.L.dctfhe_fp64_peak(self.h, C.byref(v)))
         return v.value
 
+    def dct_frontend(self, y, c1, c2, fs, idx, mean, std, round_coeffs=False):
+        """uint8 planes y [B, fs*S, fs*S], c1/c2 [B, fs*Sc, fs*Sc] -> float32 [B, C, S, S] (include/dctfhe.h dctfhe_dct_frontend)"""
+        y, c1, c2 = (np.ascontiguousarray(a, np.uint8) for a in (y, c1, c2))
+        B, S, Sc = y.shape[0], y.shape[1] // fs, c1.shape[1] // fs
+        ii = [np.ascontiguousarray(i, np.int32) for i in idx]
+        mean, std = np.ascontiguousarray(mean, np.float32), np.ascontiguousarray(std, np.float32)
+        C_ = sum(i.size for i in ii)
+        assert mean.size == std.size == C_ and y.shape == (B, fs * S, fs * S) and c1.shape == c2.shape == (B, fs * Sc, fs * Sc)
+        out = np.empty((B, C_, S, S), np.float32)
+        check(self.L.dctfhe_dct_frontend(self.h, ptr(y), ptr(c1), ptr(c2), B, S, Sc, fs, ptr(ii[0]), ii[0].size, ptr(ii[1]), ii[1].size,
+                                         ptr(ii[2]), ii[2].size, ptr(mean), ptr(std), int(bool(round_coeffs)), ptr(out)))
+        return out
+
     def conv2d(self, D, cts, batch, Cin, H, W, weight, stride, pad):
         weight = np.ascontiguousarray(weight, np.int8)
         Cout, _, KH, KW = weight.shape

@@ -180,6 +180,27 @@ def transform_dct_jpeg(img):
     return out[0], out[1], out[2]
 
 
+def device_dct_batch(ctx, images_u8, filter_size=4, image_size_dct=16, channels=24, dct_pattern="default"):
+    """The same evaluation transform with its DCT / subset / up-sampling / normalisation stages on the GPU
+    (dctfhe_dct_frontend); colour conversion, resize, crop and chroma halving stay on the host (OpenCV-defined,
+    integer).  Filter 4 (matrix2dct) path.  -> float32 [B, channels, S, S]; the numpy path stays the client-side default."""
+    if filter_size != 4:
+        raise NotImplementedError("device path: the filter-4 (matrix2dct) branch; the JPEG-domain planes come from transform_dct_jpeg on the host")
+    S = image_size_dct
+    ys, c1s, c2s = [], [], []
+    for img in images_u8:
+        side = int(filter_size * S * 1.15)
+        h, w = img.shape[:2]
+        oh, ow = (int(side * h / w), side) if w <= h else (side, int(side * w / h))
+        x = center_crop(resize_u8(img, oh, ow), filter_size * S)
+        y, cr, cb = rgb_to_ycrcb_u8(x)
+        ys.append(y); c1s.append(halve_u8(cr)); c2s.append(halve_u8(cb))       # the reference's name-swapped slots (transform_dct_size)
+    sy, scb, scr = subset_indices(channels, dct_pattern, filter_size)
+    mean, std = load_stats()
+    idx = normalize_indices(channels)
+    return ctx.dct_frontend(np.stack(ys), np.stack(c1s), np.stack(c2s), filter_size, (sy, scb, scr), mean[idx], std[idx])
+
+
 def dct_eval_transform(filter_size=4, image_size_dct=16, channels=24, dct_pattern="default"):
     """The composed evaluation transform of reference datamgr.py:192-219 (matrix2dct path for filter 4, JPEG-domain
     path for filter 8)."""

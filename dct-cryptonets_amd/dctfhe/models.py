@@ -61,6 +61,10 @@ class ResNetQ:                    # reference ResNetQDCT, backbone.py:187-288
     final_feat_dim: int
     classifier_w: np.ndarray = None   # clear nn.Linear (reference utils.py:22), [classes, feat]
     classifier_b: np.ndarray = None
+    # learned activation-quantiser scales (real value of one integer step), imported from a Brevitas checkpoint by
+    # dctfhe.checkpoint; keys: "quant_inp", "stem_relu", "stem_quant_out", ("block", i, "relu1" | "quant_out" |
+    # "BNquant_out" | "relu2"), "final".  A missing key falls back to calibration (dctfhe.compile.act_scale).
+    act_scales: dict = field(default_factory=dict)
 
 
 def _init_conv(rng, cout, cin, k):

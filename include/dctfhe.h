@@ -148,6 +148,15 @@ int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int batch, int Cin
                   const int8_t* weight /* [Cout][Cin][KH][KW] */, int Cout, int KH, int KW, int stride, int pad,
                   uint64_t* out);
 
+/* K10, client side, plaintext: the DCT front-end of reference data/cvfunctional.py:37-74 + data/cvtransforms.py:56-64,117-208 on
+ * uint8 planes (luma [batch][fs*S][fs*S]; two chroma slots [batch][fs*Sc][fs*Sc], Sc = S/2 for the 4:2:0 paths or S):
+ * blockwise orthonormal DCT-II of (pixel - 128), only the kept coefficients idx_* (row-major u*fs+v), chroma grids
+ * bilinearly up-sampled to S x S, channels concatenated luma | slot 1 | slot 2, (x - mean[c]) / std[c] in f32.
+ * round_coeffs != 0: the JPEG-domain (filter 8) path's integer coefficient planes.  out: float32 [batch][ny+n1+n2][S][S]. */
+int dctfhe_dct_frontend(dctfhe_ctx* ctx, const uint8_t* y, const uint8_t* c1, const uint8_t* c2, int batch, int S, int Sc, int fs,
+                        const int32_t* idx_y, int ny, const int32_t* idx_c1, int n1, const int32_t* idx_c2, int n2,
+                        const float* mean, const float* stdv, int round_coeffs, float* out);
+
 /* host-only validators (no GPU): parameter set / circuit blob well-formed?  0 or -1 with dctfhe_last_error() */
 int dctfhe_params_check(const dctfhe_params* params);
 int dctfhe_circuit_validate(const void* blob, size_t size);

@@ -188,3 +188,29 @@ def test_input_on_a_key_prefix_and_tail_guard():
             sess.upload(cts)
     finally:
         qm.close()
+
+
+def test_imported_checkpoint_runs_encrypted(tmp_path):
+    """SURVEY 8f-1 end to end: a `best.tar` in the reference's layout (train.py:82-89; DataParallel + `feature.trunk.<i>` keys,
+    Brevitas activation thresholds included) -> load_checkpoint -> compile with the imported scales -> encrypted run == the
+    integer circuit."""
+    import torch
+    from dctfhe import checkpoint, models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    from test_checkpoint import _fake_state
+    rng = np.random.default_rng(4)
+    model = models.tiny_resnet_q()
+    path = str(tmp_path / "best.tar")
+    torch.save({"epoch": 1, "state": _fake_state(model, rng), "prec1": 50.0, "prec5": 90.0, "optimizer": {}}, path)
+    meta, unused = checkpoint.load_checkpoint(path, model)
+    assert meta["epoch"] == 1 and all("num_batches_tracked" in k for k in unused)
+    assert len(model.act_scales) == 4 + 3 * len(model.blocks) + 1      # stem x3 + final, 3 per block, + the one 1x1-shortcut block's BNquant_out
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=6, param_set=P.test_params())
+    try:
+        assert abs(qm.compiled.in_scale - 2.0 / 8) < 1e-7          # the checkpoint's quant_inp threshold, not a re-calibrated one
+        qm.fhe_circuit.keygen(seed=12)
+        q = qm.quantize_input(calib[:4])
+        assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
+    finally:
+        qm.close()
