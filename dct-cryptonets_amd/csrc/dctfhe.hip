@@ -180,6 +180,9 @@ constexpr int groups_for() {
   constexpr int by_lds = (160 * 1024 - G::TW_BYTES) / G::GROUP_BYTES;
   int g = G::T >= 256 ? 1 : 256 / G::T;   // two 256-thread workgroups per CU beat one of 512 (+10..20%, profiles/r01_exp_wg.log)
   while (g > 1 && g > by_lds) g >>= 1;
+  // ... and when two such workgroups do not fit the LDS together (both mask polynomials of a k = 2, l = 2 tier live there),
+  // smaller workgroups keep the CU at two waves per SIMD
+  while (g > 1 && 2 * (G::TW_BYTES + g * G::GROUP_BYTES) > 160 * 1024) g >>= 1;
   return g;
 }
 

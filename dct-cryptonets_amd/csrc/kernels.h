@@ -436,7 +436,11 @@ pbs_kernel(pbs_launch a) {
   A.wtab = a.wtab;
   if constexpr (G::TWIST_LDS) A.twist = tw + G::F::TW_TOTAL; else A.twist = a.tw + G::F::TW_TOTAL;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
+#if defined(DCTFHE_ABLATE_BARRIER)   // timing experiments only (tools/exp_pbs.hip): no workgroup barriers, wrong results
+  if constexpr (true) {
+#else
   if constexpr (T <= 64) {
+#endif
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
     // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
     pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });

@@ -84,7 +84,9 @@ struct pbs_geom {
   static constexpr int KEY_BLOCKS = MB ? 3 : 1;        // key-bit-sized blocks read per loop iteration
   static constexpr int RL = F::radix(F::S - 1);        // radix of the last pass
   static constexpr int NG = P / RL;                    // small transforms per thread in the last pass
-  static constexpr int NL_AUTO = (K >= 2 || L >= 3) ? 1 : 0;
+  // k = 2 with two levels: both mask polynomials in LDS -- with one the kernel spilled 71 VGPRs (216 B/lane of scratch, 78 GB
+  // written per launch of 12 288 ciphertexts: profiles/r02_pmc_tiers.txt)
+  static constexpr int NL_AUTO = (K >= 2 && L >= 2) ? 2 : (K >= 2 || L >= 3) ? 1 : 0;
   static constexpr int NL = PBS_LDS_POLYS < 0 ? NL_AUTO : (PBS_LDS_POLYS < K ? PBS_LDS_POLYS : K);
   // ACC32: a one-level gadget rounds every accumulator coefficient to 2^-(beta+1) >= 2^-29 of the torus at each step anyway
   // (beta <= 28 enforced by the library for such tiers), so the accumulator of a one-level tier is kept as the top 32 bits:
