@@ -21,7 +21,7 @@
 #include <stdint.h>
 #include <type_traits>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define HD __host__ __device__ __forceinline__
 #else
 #define HD inline __attribute__((always_inline))
@@ -36,16 +36,6 @@
 #define DCTFHE_FFT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #else
 #define DCTFHE_FFT_SCHED_BARRIER() ((void)0)
-#endif
-
-// experiment switch: interleave exchange stores with twiddle arithmetic (see fft_forward_n)
-#ifndef DCTFHE_DS_INTERLEAVE
-#define DCTFHE_DS_INTERLEAVE 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DCTFHE_DS_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define DCTFHE_DS_FENCE() ((void)0)
 #endif
 
 namespace dctfhe {
@@ -318,27 +308,7 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
       const cplx b = tw[G::tw_offset(i) + (t % W)];
       const cplx run0 = (i == 0) ? twist : cmk(1.0, 0.0);
       if constexpr (W <= 64) wsync(); else sync();      // nobody still gathers from the buffers about to be written
-#if DCTFHE_SHARED_TWIDDLES && DCTFHE_DS_INTERLEAVE
-      // as below, but every output goes to the exchange buffer as soon as its twiddle is applied, fenced so that the
-      // scheduler keeps the order: the LDS store path (13 cycles per ds_write_b128 and wave) drains under the twiddle
-      // arithmetic of the next outputs instead of stalling the wave behind a burst of 2 * P stores
-      cplx y[NP][P];
-      static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; small_dft<P, 1, -1>::run(v[u], y[u]); });
-      {
-        cplx run = run0;
-        DCTFHE_DS_FENCE();
-        static_for<0, R>([&](auto K) {
-          constexpr int k = decltype(K)::value;
-          if constexpr (k > 0) run = cmul(run, b);
-          static_for<0, NP>([&](auto U) {
-            constexpr int u = decltype(U)::value;
-            if constexpr (k > 0 || i == 0) y[u][k] = cmul(y[u][k], run);
-            exch[u * G::EXCH_ELEMS + G::skew(pass_addr<LOGM, P, i>(t, k))] = y[u][k];
-          });
-          DCTFHE_DS_FENCE();
-        });
-      }
-#elif DCTFHE_SHARED_TWIDDLES
+#if DCTFHE_SHARED_TWIDDLES
       // butterflies of all NP polynomials, then ONE running twiddle product applied to all of them (the chain costs
       // as much as applying it: 4 f64 instructions per step), then the scatters
       cplx y[NP][P];
@@ -429,39 +399,6 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
         static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; v[u][k] = cmulc(v[u][k], run); });
       });
     }
-#endif
-#if DCTFHE_DS_INTERLEAVE
-    if constexpr (NP == 2 && R == P && P == 8 && i > 0) {
-      // the scatter of polynomial 0 drains under the butterflies of polynomial 1, piece by piece (fenced: the scheduler
-      // otherwise gathers all 16 stores behind all the arithmetic and the wave stalls on the LDS store path)
-      cplx y0[P], y1[P], e[4], o[4];
-      small_dft<P, 1, +1>::run(v[0], y0);
-      cplx* ex0 = exch;
-      cplx* ex1 = exch + G::EXCH_ELEMS;
-      auto put0 = [&](auto J) { constexpr int j = decltype(J)::value; ex0[G::skew(pass_addr<LOGM, P, i>(t, j))] = y0[j]; };
-      DCTFHE_DS_FENCE();
-      small_dft<4, 2, +1>::run(v[1], e);
-      put0(std::integral_constant<int, 0>{}); put0(std::integral_constant<int, 1>{});
-      DCTFHE_DS_FENCE();
-      small_dft<4, 2, +1>::run(v[1] + 1, o);
-      put0(std::integral_constant<int, 2>{}); put0(std::integral_constant<int, 3>{});
-      DCTFHE_DS_FENCE();
-      static_for<0, 2>([&](auto K) {
-        constexpr int k = decltype(K)::value;
-        const cplx tt = mul_root64<k*(64 / 8), +1>(o[k]);
-        y1[k] = cadd(e[k], tt); y1[k + 4] = csub(e[k], tt);
-      });
-      put0(std::integral_constant<int, 4>{}); put0(std::integral_constant<int, 5>{});
-      DCTFHE_DS_FENCE();
-      static_for<2, 4>([&](auto K) {
-        constexpr int k = decltype(K)::value;
-        const cplx tt = mul_root64<k*(64 / 8), +1>(o[k]);
-        y1[k] = cadd(e[k], tt); y1[k + 4] = csub(e[k], tt);
-      });
-      put0(std::integral_constant<int, 6>{}); put0(std::integral_constant<int, 7>{});
-      DCTFHE_DS_FENCE();
-      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex1[G::skew(pass_addr<LOGM, P, i>(t, j))] = y1[j]; });
-    } else
 #endif
     static_for<0, NP>([&](auto U) {
       constexpr int u = decltype(U)::value;
