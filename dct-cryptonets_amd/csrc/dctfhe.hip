@@ -141,6 +141,9 @@ struct dctfhe_session {
   std::vector<uint64_t*> d_tensor;
   std::vector<std::pair<size_t, uint64_t*>> owned;
   std::vector<size_t> tensor_words;
+  // encrypted tensors are stored at their effective dimension: row stride t_L[t] words = t_L[t]-1 mask words + the body;
+  // t_deff[t] <= t_L[t]-1 is how many leading mask words may be non-zero.  Clear mode: one word per element.
+  std::vector<size_t> t_L, t_deff;
   // scratch for LUT sites
   size_t chunk = 0;
   uint8_t* d_digits = nullptr;
@@ -687,12 +690,16 @@ enum { CAT_LINEAR = 100, CAT_KS = 101 };  // 0..7: bootstrap of tier i
 // deff: mask words beyond it are known to be zero in every input (0 or >= D: no such knowledge).  The key switch then
 // runs on the first deff rows of the key only -- the same result bit for bit, deff/D of the work.
 static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t count, int shift, uint8_t* d_digits, uint64_t* d_bodies,
-                         uint64_t* d_small, Timers* tm, int deff = 0) {
+                         uint64_t* d_small, Timers* tm, int deff = 0, size_t L = 0, uint64_t body_add = 0) {
   const dctfhe_tier& t = K->p.tiers[tier];
   TierKeys& tk = K->tiers[tier];
   const int D = K->p.D;
+  if (L == 0) L = (size_t)D + 1;                 // row stride of the input ciphertexts (body at L-1); host format by default
+  const int Dmax = (int)std::min<size_t>(L - 1, (size_t)D);
   hipStream_t st = K->ctx->stream;
-  int De = (deff > 0 && deff < D && tk.d_kskT && (deff * t.lk) % 64 == 0) ? deff : D;
+  int De = (deff > 0 && deff < Dmax && tk.d_kskT && (deff * t.lk) % 64 == 0) ? deff : Dmax;
+  if (!tk.d_kskT && De != D) return fail("key switch: the integer-VALU path needs full-width rows");
+  if (tk.d_kskT && (De * t.lk) % 64 != 0) return fail("key switch: %d rows x %d levels is not a multiple of 64", De, t.lk);
   const uint64_t* colsum = tk.d_colsum;
   if (De < D) {
     auto it = tk.colsum_eff->find(De);
@@ -708,11 +715,11 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
   const int h = tm ? tm->begin(CAT_KS) : -1;
   const size_t total = count * (size_t)De;
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
-  hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, D, De, shift, t.lk, t.betak, d_digits, d_bodies);
+  hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, L, De, shift, body_add, t.lk, t.betak, d_digits, d_bodies);
   if (tk.d_kskT) {   // matrix-core path: i8 digits x signed byte limbs of the key
     dim3 g2((unsigned)(tk.ncol_pad / 128), (unsigned)((count + 127) / 128));
     hipLaunchKernelGGL(k_ks_mfma, g2, dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, colsum, t.n, t.betak, d_small);
-  } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64): integer VALU GEMM
+  } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64, betak = 8): integer VALU GEMM
     constexpr int CT = 16;
     dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));
     hipLaunchKernelGGL(k_ks_gemm<CT>, g2, dim3(256), 0, st, d_digits, d_bodies, count, D * t.lk, tk.d_ksk, tk.d_colsum, t.n, t.betak, d_small);
@@ -723,25 +730,28 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
 }
 
 static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t count, const int64_t* d_tables, int w, const int32_t* d_idx,
-                   int hw, int nchan, size_t e_offset, uint64_t* d_out, int accumulate, uint64_t body_add, Timers* tm) {
+                   int hw, int nchan, size_t e_offset, uint64_t* d_out, int accumulate, uint64_t body_add, Timers* tm, size_t L_out = 0) {
   const dctfhe_tier& t = K->p.tiers[tier];
   pbs_launch a;
   a.cts_small = d_small; a.count = count; a.n = t.n; a.beta = t.beta;
   a.bsk = K->tiers[tier].d_bsk; a.tw = K->tiers[tier].d_tw; a.wtab = K->tiers[tier].d_wtab;
   a.tables = d_tables; a.w = w; a.table_idx = d_idx; a.hw = hw; a.nchan = nchan; a.e_offset = e_offset;
-  a.out = d_out; a.D_out = K->p.D; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy; a.bsk_wrap = 0; a.pf_parts = 16;
+  const int ring = t.k << t.logN;
+  if (L_out == 0) L_out = (size_t)K->p.D + 1;
+  if (L_out < (size_t)ring + 1) return fail("bootstrap output rows of %zu words cannot hold a ring of %d", L_out, ring);
+  a.out = d_out; a.D_out = (int)L_out - 1; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy; a.bsk_wrap = 0; a.pf_parts = 16;
   const int h = tm ? tm->begin(tier) : -1;
   CHK(launch_pbs(t, a, K->ctx->stream));
   if (tm) tm->end(h);
   return 0;
 }
 
-static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t L, const int8_t* d_w, int Cout, int KH,
-                      int KW, int stride, int pad, uint64_t* out, size_t deff = 0) {
+static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t Lin, size_t deff, const int8_t* d_w, int Cout, int KH,
+                      int KW, int stride, int pad, uint64_t* out, size_t Lout) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   constexpr int COT = 16;
-  dim3 grid((unsigned)((L + 255) / 256), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + COT - 1) / COT));
-  hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, L, (deff > 0 && deff < L - 1) ? deff : L - 1, d_w, Cout, KH, KW, stride, pad, Ho, Wo, out);
+  dim3 grid((unsigned)((Lout + 255) / 256), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + COT - 1) / COT));
+  hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, Lin, deff, d_w, Cout, KH, KW, stride, pad, Ho, Wo, Lout, out);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -750,26 +760,34 @@ static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::mi
 
 // exact rounding + table look-up on `count` ciphertexts, in place on d_work (already shifted / offset)
 struct LutScratch { uint8_t* digits = nullptr; uint64_t* bodies = nullptr; uint64_t* small = nullptr; int64_t* bit_tables = nullptr; size_t chunk = 0; };
-// rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe)
-static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, uint64_t* d_work, size_t count, int p, int r,
-                         const int64_t* d_tables, int w, const int32_t* d_idx, int hw, int nchan, const LutScratch& sc, Timers* tm, int deff = 0) {
-  const size_t L = (size_t)K->p.D + 1;
-  // the rounding steps add bit-tier outputs (dimension k*N of that tier) to the working ciphertexts
-  auto ring = [&](int tier) { return tier >= 0 ? (K->p.tiers[tier].k << K->p.tiers[tier].logN) : 0; };
-  if (deff > 0 && r > 0) deff = std::max(deff, std::max(ring(bit_tier), coarse_from < r ? ring(bit_tier_coarse) : 0));
+// rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe).
+// r > 0: in place on d_work (rows of Lw words, already shifted / offset; the first `deff` mask words may be non-zero).
+// r == 0: nothing modifies the input, so the key switch reads d_src (rows of Ls words) directly with the site's shift and
+// body offset applied on the fly, and the table bootstrap writes d_work -- no copy of the tensor at all.
+static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, const uint64_t* d_src, size_t Ls, int shift,
+                         uint64_t body_add, uint64_t* d_work, size_t Lw, size_t count, int p, int r, const int64_t* d_tables, int w, const int32_t* d_idx,
+                         int hw, int nchan, const LutScratch& sc, Timers* tm, int deff = 0) {
   for (size_t c0 = 0; c0 < count; c0 += sc.chunk) {
     const size_t cn = std::min(sc.chunk, count - c0);
-    uint64_t* w0 = d_work + c0 * L;
+    uint64_t* w0 = d_work + c0 * Lw;
     for (int i = 0; i < r; i++) {
       const int bt = (bit_tier_coarse >= 0 && i >= coarse_from) ? bit_tier_coarse : bit_tier;
-      CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm, deff));
+      CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm, deff, Lw));
       const int vlog = 62 - p + i;
-      CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm));
+      CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm, Lw));
     }
-    CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm, deff));
-    CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm));
+    if (r > 0) CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm, deff, Lw));
+    else       CHK(dev_keyswitch(K, tab_tier, d_src + c0 * Ls, cn, shift, sc.digits, sc.bodies, sc.small, tm, deff, Ls, body_add));
+    CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm, Lw));
   }
   return 0;
+}
+// the mask words a rounding chain touches: its input's, and the rings of the bit tiers whose outputs it accumulates
+static int round_chain_deff(const dctfhe_keys* K, int src_deff, int bit_tier, int bit_tier_coarse, int coarse_from, int r) {
+  auto ring = [&](int tier) { return tier >= 0 ? (K->p.tiers[tier].k << K->p.tiers[tier].logN) : 0; };
+  int d = src_deff;
+  if (r > 0) d = std::max(d, std::max(coarse_from > 0 ? ring(bit_tier) : 0, coarse_from < r ? ring(bit_tier_coarse) : 0));
+  return d;
 }
 
 static int alloc_lut_scratch(dctfhe_keys* K, size_t chunk, LutScratch* sc) {
@@ -872,10 +890,12 @@ extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int bit_ti
   LutScratchOwner sc;
   CHK(alloc_lut_scratch(K, std::min<size_t>(count, 4096), &sc.s));
   if (r > 0) {
-    hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work.as<uint64_t>(), d_work.as<uint64_t>(), count, L, 0, 1ULL << (63 - p + r - 1));
+    hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * L)), dim3(256), 0, ctx->stream, d_work.as<uint64_t>(), L, L - 1, d_work.as<uint64_t>(), L, count, L - 1, 0,
+                       1ULL << (63 - p + r - 1));
     HIPCHK(hipGetLastError());
   }
-  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work.as<uint64_t>(), count, p, r, d_tab.as<int64_t>(), w, d_idx.as<int32_t>(), 1, 1, sc.s, nullptr));
+  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work.as<uint64_t>(), L, 0, 0, d_work.as<uint64_t>(), L, count, p, r, d_tab.as<int64_t>(), w,
+                    d_idx.as<int32_t>(), 1, 1, sc.s, nullptr));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cts_out, d_work.p, count * L * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -896,7 +916,7 @@ extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int bat
   HIPCHK(d_w.alloc(nw));
   HIPCHK(hipMemcpy(d_in.p, in, nin * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_w.p, weight, nw, hipMemcpyHostToDevice));
-  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, d_w.as<int8_t>(), Cout, KH, KW, stride, pad, d_out.as<uint64_t>()));
+  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, d_out.p, nout * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -1098,7 +1118,6 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
   std::unique_ptr<dctfhe_session> s(new dctfhe_session);
   s->ctx = ctx; s->circ = circ; s->keys = keys; s->batch = batch;
   s->D = keys ? keys->p.D : 0;
-  const size_t L = (size_t)s->D + 1;
   // validate tiers named by the circuit
   if (keys)
     for (size_t i = 0; i < circ->ops.size(); i++) {
@@ -1122,9 +1141,40 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
   last_use[circ->input_tensor] = 1 << 30;
   s->d_tensor.assign(nt, nullptr);
   s->tensor_words.assign(nt, 0);
+  // row layout per tensor.  Encrypted: a tensor is stored at its effective dimension -- the compiler's `deff` (ip[10] of the
+  // consuming / producing op: mask words beyond it are zero in every ciphertext of the tensor); the output of a look-up is as
+  // wide as its table tier's ring, or as the rounding chain that works in place on it.  75 % of a ResNet tensor used to be
+  // stored, written and streamed zeros.
+  s->t_L.assign(nt, 1);
+  s->t_deff.assign(nt, 0);
+  if (keys) {
+    const size_t D = (size_t)s->D;
+    // (the matrix-core key switch walks the key in steps of 64 rows: an effective dimension it cannot take is kept at full width)
+    auto clampd = [&](int d) { return (size_t)((d > 0 && (size_t)d < D && d % 64 == 0) ? d : D); };
+    std::vector<char> known(nt, 0);
+    auto set = [&](int t, size_t deff, size_t width) { s->t_deff[t] = deff; s->t_L[t] = std::max(deff, width) + 1; known[t] = 1; };
+    for (const Op& o : circ->ops)
+      if (o.src0 == circ->input_tensor) { set(circ->input_tensor, clampd(o.ip[10]), 0); break; }
+    if (!known[circ->input_tensor]) set(circ->input_tensor, D, 0);
+    for (size_t i = 0; i < circ->ops.size(); i++) {
+      const Op& o = circ->ops[i];
+      if (!known[o.src0] || (o.type == OP_ADD && !known[o.src1])) return fail("op %zu reads a tensor no earlier op wrote", i);
+      if (o.type == OP_LUT) {
+        const int r = o.ip[9] ? 0 : o.ip[1], tt = o.ip[4];
+        const size_t ring = (size_t)keys->p.tiers[tt].k << keys->p.tiers[tt].logN;
+        if (clampd(o.ip[10]) < s->t_deff[o.src0]) return fail("op %zu: look-up compiled for effective dimension %d, its input has %zu", i, o.ip[10], s->t_deff[o.src0]);
+        const size_t chain = r > 0 ? (size_t)round_chain_deff(keys, (int)clampd(o.ip[10]), o.ip[5], o.ip[7], o.ip[8], r) : 0;
+        set(o.dst, ring, chain);
+      } else if (o.type == OP_ADD) {
+        set(o.dst, std::max(s->t_deff[o.src0], s->t_deff[o.src1]), 0);
+      } else {
+        set(o.dst, s->t_deff[o.src0], 0);
+      }
+    }
+  }
   for (int t = 0; t < nt; t++) {
     const TensorShape& x = circ->tensors[t];
-    s->tensor_words[t] = (size_t)batch * x.C * x.H * x.W * L;
+    s->tensor_words[t] = (size_t)batch * x.C * x.H * x.W * s->t_L[t];
   }
   std::vector<std::pair<size_t, uint64_t*>> freelist;
   auto get = [&](size_t words, uint64_t** p) -> int {
@@ -1178,28 +1228,35 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
 extern "C" int dctfhe_session_destroy(dctfhe_session* s) { delete s; return 0; }
 
 extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) {
+  if (!s || !cts_in) return fail("dctfhe_session_upload: null argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->input_tensor;
-  HIPCHK(hipMemcpyAsync(s->d_tensor[t], cts_in, s->tensor_words[t] * 8, hipMemcpyHostToDevice, s->ctx->stream));
-  // the circuit was compiled for inputs that are zero beyond their effective dimension (client encryption on a key prefix,
-  // dctfhe_params.input_dim): the key switch and the convolutions skip that tail, so make sure it really is empty
-  if (s->keys) {
-    int deff = 0;
-    for (const Op& o : s->circ->ops)
-      if (o.src0 == t) { deff = o.ip[10]; break; }
-    if (deff > 0 && deff < s->D) {
-      const size_t count = s->tensor_words[t] / (size_t)(s->D + 1);
-      HIPCHK(hipMemsetAsync(s->d_overflow, 0, sizeof(int), s->ctx->stream));
-      hipLaunchKernelGGL(k_tail_nonzero, dim3(ew_grid(count * (size_t)(s->D - deff))), dim3(256), 0, s->ctx->stream, s->d_tensor[t], count, s->D, deff,
-                         s->d_overflow);
-      HIPCHK(hipGetLastError());
-      int bad = 0;
-      HIPCHK(hipMemcpyAsync(&bad, s->d_overflow, sizeof bad, hipMemcpyDeviceToHost, s->ctx->stream));
-      HIPCHK(hipStreamSynchronize(s->ctx->stream));
-      if (bad) return fail("input ciphertexts have non-zero mask words beyond %d: encrypt them with these parameters (input_dim)", deff);
-    }
+  hipStream_t st = s->ctx->stream;
+  if (!s->keys) {      // clear mode: one word per element, stored as given
+    HIPCHK(hipMemcpyAsync(s->d_tensor[t], cts_in, s->tensor_words[t] * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
   }
-  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  // host rows are D+1 words; the tensor is stored at its effective dimension.  The circuit was compiled for inputs that are
+  // zero beyond it (client encryption on a key prefix, dctfhe_params.input_dim): the key switch and the convolutions never
+  // look at that tail, so make sure it really is empty before dropping it
+  const size_t Lh = (size_t)s->D + 1, Ls = s->t_L[t], deff = s->t_deff[t];
+  const size_t count = s->tensor_words[t] / Ls;
+  DevBuf tmp;
+  HIPCHK(tmp.alloc(count * Lh * 8));
+  HIPCHK(hipMemcpyAsync(tmp.p, cts_in, count * Lh * 8, hipMemcpyHostToDevice, st));
+  if (deff < (size_t)s->D) {
+    HIPCHK(hipMemsetAsync(s->d_overflow, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_tail_nonzero, dim3(ew_grid(count * ((size_t)s->D - deff))), dim3(256), 0, st, tmp.as<uint64_t>(), count, s->D, (int)deff, s->d_overflow);
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, s->d_overflow, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (bad) return fail("input ciphertexts have non-zero mask words beyond %zu: encrypt them with these parameters (input_dim)", deff);
+  }
+  hipLaunchKernelGGL(k_restride, dim3(ew_grid(count * Ls)), dim3(256), 0, st, tmp.as<uint64_t>(), Lh, s->d_tensor[t], Ls, count, deff);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
 extern "C" int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const double* sigma_per_op, int n_ops) {
@@ -1211,10 +1268,23 @@ extern "C" int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const 
 }
 
 extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
+  if (!s || !cts_out) return fail("dctfhe_session_download: null argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->output_tensor;
-  HIPCHK(hipMemcpyAsync(cts_out, s->d_tensor[t], s->tensor_words[t] * 8, hipMemcpyDeviceToHost, s->ctx->stream));
-  HIPCHK(hipStreamSynchronize(s->ctx->stream));
+  hipStream_t st = s->ctx->stream;
+  if (!s->keys) {
+    HIPCHK(hipMemcpyAsync(cts_out, s->d_tensor[t], s->tensor_words[t] * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  const size_t Lh = (size_t)s->D + 1, Ls = s->t_L[t];
+  const size_t count = s->tensor_words[t] / Ls;
+  DevBuf tmp;      // back to host rows of D+1 words, zero tail
+  HIPCHK(tmp.alloc(count * Lh * 8));
+  hipLaunchKernelGGL(k_restride, dim3(ew_grid(count * Lh)), dim3(256), 0, st, s->d_tensor[t], Ls, tmp.as<uint64_t>(), Lh, count, s->t_deff[t]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(cts_out, tmp.p, count * Lh * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -1223,7 +1293,6 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
   hipStream_t st = s->ctx->stream;
   dctfhe_circuit* c = s->circ;
   dctfhe_keys* K = s->keys;
-  const size_t L = (size_t)s->D + 1;
   const int B = s->batch;
   Timers tm{st, timing != nullptr, &s->ev_pool, {}};
   const hipEvent_t e0 = tm.take(), e1 = tm.take();
@@ -1236,16 +1305,19 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
     const TensorShape& d = c->tensors[o.dst];
     uint64_t* src = s->d_tensor[o.src0];
     uint64_t* dst = s->d_tensor[o.dst];
+    const size_t Ls = s->t_L[o.src0], Ld = s->t_L[o.dst], ds = s->t_deff[o.src0];
     switch (o.type) {
       case OP_CONV: {
         const int h = tm.begin(CAT_LINEAR);
-        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, L, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst, K ? (size_t)o.ip[10] : 0));
+        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, Ls, ds, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst, Ld));
         tm.end(h);
         break;
       }
       case OP_ADD: {
         const int h = tm.begin(CAT_LINEAR);
-        hipLaunchKernelGGL(k_add, dim3(ew_grid(s->tensor_words[o.dst])), dim3(256), 0, st, src, s->d_tensor[o.src1], dst, s->tensor_words[o.dst]);
+        const size_t count = s->tensor_words[o.dst] / Ld;
+        hipLaunchKernelGGL(k_add, dim3(ew_grid(s->tensor_words[o.dst])), dim3(256), 0, st, src, Ls, ds, s->d_tensor[o.src1], s->t_L[o.src1], s->t_deff[o.src1], dst, Ld,
+                           count);
         HIPCHK(hipGetLastError());
         tm.end(h);
         break;
@@ -1253,7 +1325,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
       case OP_SUMPOOL: {
         const int h = tm.begin(CAT_LINEAR);
         const size_t tw = s->tensor_words[o.dst];
-        hipLaunchKernelGGL(k_sum_pool, dim3(ew_grid(tw)), dim3(256), 0, st, src, a.C, a.H, a.W, L, o.ip[0], d.H, d.W, dst, tw);
+        hipLaunchKernelGGL(k_sum_pool, dim3(ew_grid(tw)), dim3(256), 0, st, src, a.C, a.H, a.W, Ls, ds, o.ip[0], d.H, d.W, dst, Ld, tw);
         HIPCHK(hipGetLastError());
         tm.end(h);
         break;
@@ -1270,17 +1342,22 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
                              (uint64_t)(0x51D0000 + (s->sim_run << 12) + i), (int)(o.ip[9] != 0));
           HIPCHK(hipGetLastError());
         } else {
-          const int h = tm.begin(CAT_LINEAR);
-          // exact rounding: + half of what is removed, then r one-bit steps clear the low bits.  Approximate rounding
-          // (ip[9], the reference README's {"method": "approximate"}): no steps -- the low bits stay and the half-box
-          // rotation of the test vector does the rounding; + half an input unit puts the two inputs next to a rounding
-          // boundary at equal distance from it (noise beyond that distance gives the neighbouring table entry).
+          // exact rounding: + half of what is removed, then r one-bit steps clear the low bits, in place on a shifted copy of the
+          // input.  Approximate rounding (ip[9], the reference README's {"method": "approximate"}): no steps -- the low bits stay
+          // and the half-box rotation of the test vector does the rounding; + half an input unit puts the two inputs next to a
+          // rounding boundary at equal distance from it.  Without steps nothing is copied: the key switch reads the input tensor.
           const bool approx = o.ip[9] != 0 && r > 0;
+          const int steps = approx ? 0 : r;
           const uint64_t add = body_add + (approx ? (1ULL << (62 - p)) : (r > 0 ? (1ULL << (63 - p + r - 1)) : 0));
-          hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * L)), dim3(256), 0, st, src, dst, E, L, shift, add);
-          HIPCHK(hipGetLastError());
-          tm.end(h);
-          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, dst, E, p, approx ? 0 : r, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm, o.ip[10]));
+          int deff = (int)ds;
+          if (steps > 0) {
+            deff = round_chain_deff(K, (int)ds, bt, o.ip[7], o.ip[8], steps);
+            const int h = tm.begin(CAT_LINEAR);
+            hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * ((size_t)deff + 1))), dim3(256), 0, st, src, Ls, ds, dst, Ld, E, (size_t)deff, shift, add);
+            HIPCHK(hipGetLastError());
+            tm.end(h);
+          }
+          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, src, Ls, shift, add, dst, Ld, E, p, steps, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm, deff));
         }
         break;
       }

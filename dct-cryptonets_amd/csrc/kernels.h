@@ -199,14 +199,14 @@ k_bsk_fourier(const uint64_t* __restrict__ polys, size_t npoly, const cplx* __re
 // Layout digits[c][i*lk + lev] (u8).  Also copies the (shifted) body.
 // Only the first Deff mask words are decomposed (digits [count][Deff*lk]): the caller knows the rest to be zero (nested
 // keys: a ciphertext that came out of a ring of dimension kN <= Deff has a zero tail), and a zero word contributes nothing.
-__global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, int D, int Deff, int shift, int lk, int betak,
-                               uint8_t* __restrict__ digits, uint64_t* __restrict__ bodies) {
+__global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, size_t L /* row stride in words; body at L-1 */, int Deff, int shift,
+                               uint64_t body_add, int lk, int betak, uint8_t* __restrict__ digits, uint64_t* __restrict__ bodies) {
   const size_t total = count * (size_t)Deff;
   const int half = 1 << (betak - 1);
   for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
     const size_t c = x / Deff;
     const int i = (int)(x % Deff);
-    const uint64_t v = cts[c * (size_t)(D + 1) + i] << shift;
+    const uint64_t v = cts[c * L + i] << shift;
     const int tot = lk * betak;
     uint64_t xx = (v + (1ULL << (63 - tot))) >> (64 - tot);
     const uint64_t B = 1ULL << betak, mask = B - 1;
@@ -219,7 +219,7 @@ __global__ void k_ks_decompose(const uint64_t* __restrict__ cts, size_t count, i
       if (d >= (uint64_t)half) { dv = (int)d - (int)B; carry = 1; } else { dv = (int)d; carry = 0; }
       dst[lev] = (uint8_t)(dv + half);
     }
-    if (i == 0) bodies[c] = cts[c * (size_t)(D + 1) + D] << shift;
+    if (i == 0) bodies[c] = (cts[c * L + L - 1] << shift) + body_add;      // the affine step of a look-up without rounding steps rides along
   }
 }
 
@@ -455,45 +455,43 @@ pbs_kernel(pbs_launch a) {
 // words, so every load is a coalesced stream of one input ciphertext.
 template <int COT>
 __global__ void __launch_bounds__(256)
-k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t L /* D+1 */, size_t Deff, const int8_t* __restrict__ wgt, int Cout,
-         int KH, int KW, int stride, int pad, int Ho, int Wo, uint64_t* __restrict__ out) {
+k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t Lin, size_t Deff, const int8_t* __restrict__ wgt, int Cout,
+         int KH, int KW, int stride, int pad, int Ho, int Wo, size_t Lout, uint64_t* __restrict__ out) {
+  // tensors are stored at their effective dimension: a row is Deff mask words (everything beyond is known to be zero and is
+  // not stored) then the body; thread Deff of a pixel handles the body word
   const size_t word = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int pix = blockIdx.y;           // b*Ho*Wo + y*Wo + x
   const int co0 = blockIdx.z * COT;
   const int b = pix / (Ho * Wo), y = (pix / Wo) % Ho, x = pix % Wo;
-  if (word >= L) return;
+  if (word >= Lout) return;
+  const bool body = word == Lout - 1;
   uint64_t acc[COT];
 #pragma unroll
   for (int c = 0; c < COT; c++) acc[c] = 0;
-  if (word >= Deff && word != L - 1) {   // mask words every input has at zero: write the zeros, read nothing (wave-uniform but for one wave)
+  if (body || word < Deff) {      // (words in [Deff, Lout-1) only exist when the output row is wider than its input: zeros)
+    const size_t iw = body ? Lin - 1 : word;
+    const uint64_t* inb = in + (size_t)b * Cin * H * W * Lin;
+    for (int ci = 0; ci < Cin; ci++)
+      for (int ky = 0; ky < KH; ky++) {
+        const int iy = y * stride + ky - pad;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < KW; kx++) {
+          const int ix = x * stride + kx - pad;
+          if (ix < 0 || ix >= W) continue;
+          const uint64_t v = inb[(((size_t)ci * H + iy) * W + ix) * Lin + iw];
 #pragma unroll
-    for (int c = 0; c < COT; c++) {
-      const int co = co0 + c;
-      if (co < Cout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * L + word] = 0;
-    }
-    return;
-  }
-  const uint64_t* inb = in + (size_t)b * Cin * H * W * L;
-  for (int ci = 0; ci < Cin; ci++)
-    for (int ky = 0; ky < KH; ky++) {
-      const int iy = y * stride + ky - pad;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < KW; kx++) {
-        const int ix = x * stride + kx - pad;
-        if (ix < 0 || ix >= W) continue;
-        const uint64_t v = inb[(((size_t)ci * H + iy) * W + ix) * L + word];
-#pragma unroll
-        for (int c = 0; c < COT; c++) {
-          const int co = co0 + c;
-          const int8_t wv = (co < Cout) ? wgt[(((size_t)co * Cin + ci) * KH + ky) * KW + kx] : (int8_t)0;  // uniform
-          acc[c] += (uint64_t)(int64_t)wv * v;
+          for (int c = 0; c < COT; c++) {
+            const int co = co0 + c;
+            const int8_t wv = (co < Cout) ? wgt[(((size_t)co * Cin + ci) * KH + ky) * KW + kx] : (int8_t)0;  // uniform
+            acc[c] += (uint64_t)(int64_t)wv * v;
+          }
         }
       }
-    }
+  }
 #pragma unroll
   for (int c = 0; c < COT; c++) {
     const int co = co0 + c;
-    if (co < Cout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * L + word] = acc[c];
+    if (co < Cout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * Lout + word] = acc[c];
   }
 }
 
@@ -507,29 +505,55 @@ __global__ void k_tail_nonzero(const uint64_t* __restrict__ cts, size_t count, i
 }
 
 // ------------------------------------------------------------------------------------------ K2 elementwise
-__global__ void k_add(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, uint64_t* __restrict__ o, size_t nwords) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+// Rows are stored at their effective dimension (mask words the compiler knows to be zero are not stored): a row of stride L
+// holds L-1 mask words and the body at L-1.  `take(row, L, d, w)` is word w of a row whose first d mask words may be non-zero.
+__device__ __forceinline__ uint64_t row_word(const uint64_t* row, size_t L, size_t d, size_t w, bool body) {
+  return body ? row[L - 1] : (w < d ? row[w] : 0);
 }
-// o = (a << shift), body += body_add   (mask words only shifted)
-__global__ void k_affine(const uint64_t* __restrict__ a, uint64_t* __restrict__ o, size_t count, size_t L, int shift, uint64_t body_add) {
-  const size_t total = count * L;
+// o = a + b; the operands may have different effective dimensions (the result has the larger)
+__global__ void k_add(const uint64_t* __restrict__ a, size_t La, size_t da, const uint64_t* __restrict__ b, size_t Lb, size_t db,
+                      uint64_t* __restrict__ o, size_t Lo, size_t count) {
+  const size_t total = count * Lo;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    uint64_t v = a[i] << shift;
-    if (i % L == L - 1) v += body_add;
-    o[i] = v;
+    const size_t c = i / Lo, w = i % Lo;
+    const bool body = w == Lo - 1;
+    o[i] = row_word(a + c * La, La, da, w, body) + row_word(b + c * Lb, Lb, db, w, body);
+  }
+}
+// o = (a << shift), body += body_add: the first nwords mask words and the body of every row (mask words only shifted); what
+// lies between nwords and the end of an output row is left alone (the table bootstrap that ends the site rewrites the row)
+__global__ void k_affine(const uint64_t* __restrict__ a, size_t La, size_t da, uint64_t* __restrict__ o, size_t Lo, size_t count, size_t nwords,
+                         int shift, uint64_t body_add) {
+  const size_t per = nwords + 1, total = count * per;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = i / per, w = i % per;
+    const bool body = w == nwords;
+    uint64_t v = row_word(a + c * La, La, da, w, body) << shift;
+    if (body) v += body_add;
+    o[c * Lo + (body ? Lo - 1 : w)] = v;
+  }
+}
+// rows of stride Ls -> rows of stride Ld: the first nwords mask words and the body; the other words of the output row are zero
+// (session upload: host rows of D+1 words -> stored rows; download: the reverse)
+__global__ void k_restride(const uint64_t* __restrict__ src, size_t Ls, uint64_t* __restrict__ dst, size_t Ld, size_t count, size_t nwords) {
+  const size_t total = count * Ld;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = i / Ld, w = i % Ld;
+    dst[i] = w == Ld - 1 ? src[c * Ls + Ls - 1] : (w < nwords ? src[c * Ls + w] : 0);
   }
 }
 // window-K sum pooling with floor semantics (reference nn.AvgPool2d(k): backbone.py:276; scale folded into the next table)
-__global__ void k_sum_pool(const uint64_t* __restrict__ in, int C, int H, int W, size_t L, int K, int Ho, int Wo, uint64_t* __restrict__ out,
-                           size_t total_words) {
+__global__ void k_sum_pool(const uint64_t* __restrict__ in, int C, int H, int W, size_t Lin, size_t din, int K, int Ho, int Wo,
+                           uint64_t* __restrict__ out, size_t Lout, size_t total_words) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_words; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t word = i % L;
-    size_t e = i / L;
+    const size_t word = i % Lout;
+    const bool body = word == Lout - 1;
+    size_t e = i / Lout;
     const int x = (int)(e % Wo); e /= Wo;
     const int y = (int)(e % Ho); e /= Ho;  // e = b*C + c
     uint64_t s = 0;
     for (int ky = 0; ky < K; ky++)
-      for (int kx = 0; kx < K; kx++) s += in[((e * H + (size_t)(y * K + ky)) * W + (size_t)(x * K + kx)) * L + word];
+      for (int kx = 0; kx < K; kx++) s += row_word(in + ((e * H + (size_t)(y * K + ky)) * W + (size_t)(x * K + kx)) * Lin, Lin, din, word, body);
     out[i] = s;
   }
 }

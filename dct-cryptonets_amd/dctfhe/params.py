@@ -131,7 +131,11 @@ def default_params():
     output is subtracted from a p-bit accumulator."""
     t6 = TierSpec("T6", n=832, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
     t5 = TierSpec("T5", n=832, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
-    t4 = TierSpec("T4", n=832, k=1, logN=11, l=1, beta=23, lk=6, betak=3, ksk_share=0, unroll=2)
+    # T4 / T4r look up 4-bit values (half-box 2^-6, four times the 6-bit tiers'): they afford a shorter small key -- and the
+    # blind rotation is linear in n -- at the price of key-switch keys of their own (prefixes of the same small key, noise of
+    # their own dimension).  752 / 792 are the smallest (steps of 8) that keep every site of the benchmark circuits at the
+    # worst-site level of the 832-bit tiers (tools: the search behind profiles/r02_param_search.log).
+    t4 = TierSpec("T4", n=752, k=1, logN=11, l=1, beta=23, lk=6, betak=3, unroll=2)
     b = TierSpec("B", n=584, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
@@ -142,7 +146,7 @@ def default_params():
     ba = TierSpec("Ba", n=584, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
-    t4r = TierSpec("T4r", n=832, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=0)
+    t4r = TierSpec("T4r", n=792, k=1, logN=11, l=3, beta=12, lk=6, betak=3)
     # T5a: one-level twin of T5; the 5-bit residual-sum table is split the same way (T5a + T4r ~0.9x of T5)
     t5a = TierSpec("T5a", n=832, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
