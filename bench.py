@@ -91,12 +91,12 @@ def conv_macs_of(compiled):
     return macs
 
 
-def cpu_baseline(compiled, max_threads=16, target_s_per_tier=2.5):
+def cpu_baseline(compiled, max_threads=16, target_s_per_tier=4.0):
     """Times the CPU oracle (oracle/tfhe_ref.c, the C twin; kind "port" -- the reference's own CPU path lives in absent
     third-party wheels) on a bounded sample of the same workload and scales by the circuit's counts.  Sample, per parameter
     tier the circuit uses: `threads x reps` FULL bootstraps (all n blind-rotate iterations; the key is random numbers of the
     right shape, timing does not depend on its values) and as many key switches over the effective input dimension; plus one
-    3x3 ciphertext convolution, scaled by MACs.  About 15 s of CPU work."""
+    3x3 ciphertext convolution, scaled by MACs.  About 15-25 s of CPU work."""
     import numpy as np
     from oracle import ref_loader as R
     R.build()
@@ -120,7 +120,7 @@ def cpu_baseline(compiled, max_threads=16, target_s_per_tier=2.5):
         t0 = time.time()
         R.pbs(small, bskf, None, t.k, t.N, t.l, t.beta, table, 4, None, D)               # also warms the FFT plan
         one = time.time() - t0
-        reps = int(max(1, min(8, target_s_per_tier / max(one, 1e-3))))
+        reps = int(max(1, min(32, target_s_per_tier / max(one, 1e-3))))
         small = rng.integers(0, 2 ** 64, (threads * reps, t.n + 1), dtype=np.uint64)
         t0 = time.time()
         R.pbs(small, bskf, None, t.k, t.N, t.l, t.beta, table, 4, None, D)

@@ -717,8 +717,9 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
   hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, L, De, shift, body_add, t.lk, t.betak, d_digits, d_bodies);
   if (tk.d_kskT) {   // matrix-core path: i8 digits x signed byte limbs of the key
-    dim3 g2((unsigned)(tk.ncol_pad / 128), (unsigned)((count + 127) / 128));
-    hipLaunchKernelGGL(k_ks_mfma, g2, dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, colsum, t.n, t.betak, d_small);
+    const unsigned ncb = (unsigned)(tk.ncol_pad / 128), nrb = (unsigned)((count + 127) / 128), cpx = (ncb + 7) / 8;
+    hipLaunchKernelGGL(k_ks_mfma, dim3(8 * cpx * nrb), dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, tk.ncol_pad, colsum, t.n,
+                       t.betak, d_small);
   } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64, betak = 8): integer VALU GEMM
     constexpr int CT = 16;
     dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));

@@ -291,15 +291,24 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // the A and B fragments of a lane cover the same 16 k's whatever order the hardware walks them in.
 __global__ void __launch_bounds__(256)
 k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R /* rows used: Deff*lk */,
-          const int8_t* __restrict__ kskT, int ldk /* row stride of kskT: D*lk */, const uint64_t* __restrict__ colsum /* over the R rows used */,
+          const int8_t* __restrict__ kskT, int ldk /* row stride of kskT: D*lk */, int ncol_pad, const uint64_t* __restrict__ colsum /* over the R rows used */,
           int n, int betak, uint64_t* __restrict__ out) {
   constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 16;     // +16 B per row: rows land on different bank groups
   __shared__ __attribute__((aligned(16))) int8_t As[BM * LD];
   __shared__ __attribute__((aligned(16))) int8_t Bs[BN * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const size_t c0 = (size_t)blockIdx.y * BM;
-  const size_t col0 = (size_t)blockIdx.x * BN;
+  // XCD-aware tile order (1-D grid of 8 * cpx * nrb workgroups; workgroups b and b + 8 share an XCD and its 4 MB L2): every XCD
+  // owns a strip of cpx column blocks of the key and walks the ciphertext row blocks with the columns fastest, so the ~32 tiles
+  // an XCD runs at a time are ~4 row blocks x its 7 column blocks -- each K-slice of the digits serves 7 tiles out of L2 and each
+  // K-slice of the key 4-5.  (Round 1: x = column, y = row over all XCDs: the 83 MB limb key was re-read from HBM once per row
+  // block, 10.6 GB per launch.)
+  const int ncb = ncol_pad / BN, nrb = (int)((count + BM - 1) / BM), cpx = (ncb + 7) / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cb = xcd * cpx + slot % cpx, rb = slot / cpx;
+  if (cb >= ncb || rb >= nrb) return;
+  const size_t c0 = (size_t)rb * BM;
+  const size_t col0 = (size_t)cb * BN;
   v16i acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; a++)
