@@ -161,7 +161,7 @@ def _heartbeat(state, period=30.0):
 def plan_passes(req_warm, req_steps, warm_done, steps_done, pass_s, remaining_s):
     """How many more warm-up passes and timed steps fit into `remaining_s` at `pass_s` per pass.  Timed steps take priority over
     warm-up; at least one timed step always runs.  -> (warm_total, steps_total)."""
-    fit = int(max(0.0, remaining_s) // max(pass_s, 1e-6))
+    fit = 10 ** 9 if math.isinf(remaining_s) else int(max(0.0, remaining_s) // max(pass_s, 1e-6))      # --budget-s 0: no cap
     want_steps = max(0, req_steps - steps_done)
     want_warm = max(0, req_warm - warm_done) if steps_done == 0 else 0
     more_steps = min(want_steps, fit)

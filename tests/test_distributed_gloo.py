@@ -87,5 +87,7 @@ def test_bench_budget_plan():
     assert bench.plan_passes(5, 20, 1, 0, 15.0, 100.0) == (1, 6)
     # never fewer than one timed step, even with the budget already gone
     assert bench.plan_passes(5, 20, 1, 0, 15.0, -3.0) == (1, 1)
+    # --budget-s 0: no cap
+    assert bench.plan_passes(2, 7, 1, 0, 15.0, float("inf")) == (2, 7) and bench.plan_passes(0, 1, 0, 1, 60.0, float("inf")) == (0, 1)
     # --warmup 0: planned from the first timed step
     assert bench.plan_passes(0, 20, 0, 1, 15.0, 100.0) == (0, 7)
