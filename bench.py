@@ -200,6 +200,9 @@ def main():
                     help="exact (the metric): outputs equal the integer circuit; p_error: the reference-style stochastic regime, p_error=0.01 per look-up (speed only)")
     ap.add_argument("--rounding-method", default="exact", choices=["exact", "approximate"])
     ap.add_argument("--config", default="r20_24_16", choices=sorted(CONFIGS), help="BASELINE.json config; the metric is quoted on r20_24_16")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a single-GPU box: every rank evaluates on GPU 0, collectives over gloo (same code path "
+                         "otherwise; the numbers mean nothing)")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test (CPU, gloo): ranks shard a fake batch, all_gather it and rank 0 prints a JSON line; no GPU work")
     args = ap.parse_args()
@@ -234,9 +237,14 @@ def main():
 
     state = {"phase": "setup", "passes": 0}
     _heartbeat(state)
-    torch.cuda.set_device(local_rank)
+    gpu = 0 if args.rehearse_on_one_gpu else local_rank
+    cdev = torch.device("cpu") if args.rehearse_on_one_gpu else torch.device("cuda", gpu)       # where the collectives' tensors live
+    torch.cuda.set_device(gpu)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=cdev)
 
     from dctfhe import models
     from dctfhe.quantized_module import compile_brevitas_qat_model
@@ -248,7 +256,7 @@ def main():
     model = getattr(models, factory)(bit_width=4, in_channels=in_ch, img_size=img, seed=0)
     rtb = 6 if args.rounding_method == "exact" else {"n_bits": 6, "method": "approximate"}
     t0 = time.time()
-    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=rtb, p_error=0.01, device=local_rank, tier_policy=args.tier_policy)
+    qm = compile_brevitas_qat_model(model, calib, n_bits=5, rounding_threshold_bits=rtb, p_error=0.01, device=gpu, tier_policy=args.tier_policy)
     compile_s = time.time() - t0
 
     # CPU baseline: rank 0, N = 1 only, on its own thread while the GPU warms up (ctypes drops the GIL); joined before the timed region
@@ -269,7 +277,7 @@ def main():
     # client + evaluation keys from it on its own GPU (no key traffic) and encrypts from its own counter range
     seed_t = torch.tensor(list(os.urandom(32)), dtype=torch.uint8)
     if world > 1:
-        seed_t = seed_t.cuda()
+        seed_t = seed_t.to(cdev)
         dist.broadcast(seed_t, 0)
         seed_t = seed_t.cpu()
     qm.fhe_circuit.keygen(seed=bytes(seed_t.tolist()))
@@ -303,7 +311,7 @@ def main():
         """every rank runs the same number of passes: the minimum over ranks"""
         if world == 1:
             return warm, steps
-        tt = torch.tensor([warm, steps], dtype=torch.int64, device="cuda")
+        tt = torch.tensor([warm, steps], dtype=torch.int64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MIN)
         return int(tt[0].item()), int(tt[1].item())
 
@@ -349,7 +357,7 @@ def main():
     sync()
     elapsed = time.time() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     state["phase"] = "decrypt + check"
@@ -363,8 +371,8 @@ def main():
     feats = torch.from_numpy(qm.dequantize_output(feats_q)).float()
     logits = feats @ torch.from_numpy(model.classifier_w).float().T + torch.from_numpy(model.classifier_b).float()
     if world > 1:
-        all_logits = gather_in_image_order(logits.cuda(), world).cpu()      # one RCCL all_gather, global image order
-        flags = torch.tensor([1.0 if exact else 0.0], device="cuda")
+        all_logits = gather_in_image_order(logits.to(cdev), world).cpu()      # one RCCL all_gather, global image order
+        flags = torch.tensor([1.0 if exact else 0.0], device=cdev)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         exact = bool(flags.item() > 0.5)
     else:
