@@ -531,7 +531,11 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
     // cache-resident).  Each workgroup therefore touches 1/pf_parts of the key two iterations ahead, one
     // dword per 128-byte line; issued here, right after this iteration's last key load and before the two
     // inverse transforms, the touches are long retired when the next vmcnt wait comes (vmcnt is in-order).
-    {  // straight-line on purpose: any branch or select chain here makes hipcc (ROCm 7.2) demote the register
+    // Only for the kernels whose waves share a workgroup barrier (T > 64): they walk the key in lock-step, which is what makes
+    // a line touched by one workgroup a hit for the others.  One-wave-per-ciphertext kernels (T <= 64: Ba, B) free-run; there
+    // the touches were pure overhead (round 2: Ba 66.6 -> 64.3 ms per launch of 16 384, B 131.1 -> 125.9 without them).
+    if constexpr (T > 64) {
+       // straight-line on purpose: any branch or select chain here makes hipcc (ROCm 7.2) demote the register
        // arrays to scratch (2.4 KB/lane).  The key buffer carries PBS_PF_DIST zero key bits of padding at its end.
       uint32_t acc_pf = 0;
       static_for<0, PF_ROUNDS>([&](auto Rr) { acc_pf ^= *reinterpret_cast<const uint32_t*>(pf_ptr + (size_t)decltype(Rr)::value * T * 128); });
