@@ -37,6 +37,12 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not list it, so the live FMA probe is reported beside it)
 
 
+# VALU instructions per blind-rotate loop iteration and wave, and waves per ciphertext, of the bootstrap kernels (ISA listing of the
+# shipped build: hipcc -S + tools/isa_hist.py).  key: (logN, k, l, unroll).  An iteration consumes `unroll` key bits.
+VALU_PER_ITERATION = {(13, 1, 1, 2): (2419, 8), (12, 1, 1, 2): (2337, 4), (11, 1, 1, 2): (2300, 2), (11, 1, 3, 1): (4511, 2), (10, 2, 1, 1): (2798, 1)}
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4          # wave-instructions per second: 256 CUs x 4 SIMDs, one f64 wave instruction per 4 cycles, 2.4 GHz
+
+
 def _dct_batch(n, seed):
     from dctfhe.synthetic import synthetic_dct_batch
     return synthetic_dct_batch(n, seed=seed)
@@ -446,6 +452,7 @@ def main():
             "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_SPEC_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / FP64_SPEC_TFLOPS, "peak_live_fma_probe": fp64_live,
                               "frac_of_live_probe": achieved_tf / fp64_live, "flops_per_bootstrap": flops_per_pbs},
+            "roofline_valu_issue": None,
             "time_split_ms": {"total": sum(t.total_ms for t in timings), "linear": sum(t.linear_ms for t in timings),
                               "keyswitch": sum(t.ks_ms for t in timings),
                               "pbs_by_tier": {ps.tiers[i].name: pbs_ms[i] for i in range(len(ps.tiers))}},
@@ -455,6 +462,12 @@ def main():
                             "fp64_frac_whole_pipeline": stats.flops_f64 * B * steps / elapsed / 1e12 / FP64_SPEC_TFLOPS},
             "consistency": {"wall_since_start_s": wall_now, "timed_s": elapsed, "fits_in_driver_run": bool(elapsed <= wall_now)},
         }
+        vi = VALU_PER_ITERATION.get((td.logN, td.k, td.l, unroll))
+        if vi:      # the roof these kernels actually sit under: f64 instruction issue (adds and multiplies fill as many slots as FMAs)
+            instr = vi[0] * vi[1] * (td.n / unroll) * cts_per_launch
+            res["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": instr / avg_launch_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
+                                          "frac": instr / avg_launch_s / VALU_ISSUE_PEAK, "valu_instr_per_iteration_per_wave": vi[0], "waves_per_ciphertext": vi[1],
+                                          "note": "instruction counts from the ISA of the shipped build; peak at the 2.4 GHz spec clock (the kernels hold 2.14-2.38 GHz)"}
         if cpu_box.get("res") is not None:
             res["cpu_baseline"] = cpu_box["res"]
             if "value" in res["cpu_baseline"]:
