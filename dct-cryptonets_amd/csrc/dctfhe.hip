@@ -238,7 +238,25 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
   }
   PBS_MB_CASES(X)
 #undef X
-  return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d", t.logN, t.k, t.l);
+  if (t.logN == 11 && t.k == 1 && t.l == 3 && t.unroll == 2) {
+    // the general form of the two-bit rotation (one polynomial at a time, monomial factors rebuilt per gadget row), four
+    // ciphertexts per 512-thread workgroup so that they share their key lines: 74.2 ms per 4096 against 82.3 for the one-bit
+    // chain of the same tier (profiles/r02_exp_ablations.log); its output is 0.7 bit noisier, so the compiler only uses it
+    // where the circuit's budget allows (dctfhe/params.py T4r2)
+    using G = pbs_geom<11, 1, 3, 8, 1>;
+    constexpr int GR = 4;
+    const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<11, 1, 3, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+    const unsigned grid = (unsigned)((a.count + GR - 1) / GR);
+    hipLaunchKernelGGL((pbs_kernel<11, 1, 3, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d unroll=%d", t.logN, t.k, t.l, t.unroll);
 }
 
 static int make_twiddles(const dctfhe_tier& t, std::vector<cplx>& tw) {
@@ -318,7 +336,8 @@ static int check_params(const dctfhe_params* p) {
     if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 28))
       return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 28 when l == 1: 32-bit accumulators)", i);
     if (t.unroll != 1 && t.unroll != 2) return fail("tier %d: unroll must be 1 or 2", i);
-    if (t.unroll == 2 && (t.k != 1 || t.l != 1 || t.logN < 11 || (t.n & 1))) return fail("tier %d: unroll 2 needs k = 1, l = 1, N >= 2048, n even", i);
+    if (t.unroll == 2 && (t.k != 1 || !(t.l == 1 || (t.l == 3 && t.logN == 11)) || t.logN < 11 || (t.n & 1)))
+      return fail("tier %d: unroll 2 needs k = 1, n even and l = 1 with N >= 2048, or l = 3 with N = 2048", i);
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);

@@ -422,6 +422,12 @@ def compile_model(model, calib, rounding_threshold_bits=6, n_bits=5, param_set=N
                            rounding_threshold_bits=rounding_threshold_bits, n_bits=n_bits, rounding_method=rounding_method)
     _assign_encodings(circ)
     _estimate_noise(circ)
+    if getattr(ps, "table_tier_fallback_for_w", None) and circ.worst_site_failure > ps.p_budget:
+        # a faster, noisier tier (two-bit refresh) took a site out of the budget: take the quiet twins and price again
+        ps.table_tier_for_w = {**ps.table_tier_for_w, **ps.table_tier_fallback_for_w}
+        ps.table_tier_fallback_for_w = None
+        _assign_encodings(circ)
+        _estimate_noise(circ)
     if own_catalogue and tier_policy == "exact" and circ.worst_site_failure > 1e-10:
         import warnings
         warnings.warn(f"dctfhe: a look-up site exceeds the exact-evaluation budget (p_fail/element {circ.worst_site_failure:.1e}); "

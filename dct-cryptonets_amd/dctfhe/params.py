@@ -57,6 +57,7 @@ class ParamSet:
     bit_tier: int                      # index of the one-bit (rounding) tier
     table_tier_for_w: dict             # table input width w -> tier index (outputs that feed a convolution / pooling)
     coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
+    table_tier_fallback_for_w: dict = None   # quieter (slower) tiers the compiler falls back to when a site leaves the budget
     bit_tier_coarse: int = None        # one-level twin of the bit tier for the last rounding steps of a site
     refresh_min_w: int = None          # tables this wide that feed a convolution are split: coarse look-up + small-ring refresh
     p_budget: float = 1e-12            # failure probability a single look-up site may spend on cheaper rounding steps
@@ -124,13 +125,12 @@ def default_params():
     2048 key bits: input_dim); the blind rotation is linear in n.
 
     T6 (6-bit tables after a rounded accumulator) needs N = 8192: its mod-switch noise must stay 6.4
-    sigma inside a 2^-8 half-box.  T5/T4 serve the 5-bit residual-sum tables and the 4-bit rescale
-    tables.  T6/T5 outputs feed convolutions (2-norm ~2^6.7) into p-bit accumulators, so their output noise
-    must stay near 2^-23: the f64 FFT error (~ N^2 B^2) forces small digits, hence three levels.
+    sigma inside a 2^-8 half-box.  T5a/T4 serve the 5-bit residual-sum tables and the 4-bit rescale
+    tables.  Outputs that feed convolutions (2-norm ~2^6.7) into p-bit accumulators must stay near 2^-23:
+    the f64 FFT error (~ N^2 B^2) forces small digits, hence three levels (T6, T4r, T4r2).
     B is the one-bit tier of the rounding chain: margin 1/4, so a small ring, but two levels because its
     output is subtracted from a p-bit accumulator."""
     t6 = TierSpec("T6", n=832, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
-    t5 = TierSpec("T5", n=832, k=1, logN=12, l=3, beta=12, lk=6, betak=3, ksk_share=0)
     # T4 / T4r look up 4-bit values (half-box 2^-6, four times the 6-bit tiers'): they afford a shorter small key -- and the
     # blind rotation is linear in n -- at the price of key-switch keys of their own (prefixes of the same small key, noise of
     # their own dimension).  752 / 792 are the smallest (steps of 8) that keep every site of the benchmark circuits at the
@@ -147,10 +147,16 @@ def default_params():
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
     t4r = TierSpec("T4r", n=792, k=1, logN=11, l=3, beta=12, lk=6, betak=3)
-    # T5a: one-level twin of T5; the 5-bit residual-sum table is split the same way (T5a + T4r ~0.9x of T5)
+    # T4r2: the same refresh with two key bits per iteration (general form of the two-bit rotation, csrc/pbs_core.h): 10 %
+    # fewer milliseconds per launch, output 0.7 bit noisier (three external products per pair).  The compiler takes it when every
+    # site of the circuit stays inside the budget with it (the ResNet-20 circuits do) and falls back to T4r otherwise (two
+    # sites of ResNet-18 3x32^2 would sit at 3.8e-12): ParamSet.table_tier_fallback_for_w.  Shares T4r's key-switch key.
+    t4r2 = TierSpec("T4r2", n=792, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=1, unroll=2)
+    # T5a: one-level twin of the three-level 5-bit tier; the 5-bit residual-sum table is split the same way (T5a + T4r)
     t5a = TierSpec("T5a", n=832, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
-    return ParamSet(D=8192, tiers=[t6, t5, t4, b, t6a, ba, t4r, t5a], bit_tier=3, table_tier_for_w={4: 6, 5: 1, 6: 0},
-                    coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5, input_dim=2048)
+    # (a table of 5 or 6 input bits that feeds a convolution without the split would run on T6; with refresh_min_w = 5 none does)
+    return ParamSet(D=8192, tiers=[t6, t4r, t4, b, t6a, ba, t4r2, t5a], bit_tier=3, table_tier_for_w={4: 6, 6: 0},
+                    table_tier_fallback_for_w={4: 1}, coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5, input_dim=2048)
 
 
 def params_for_p_error(p_error=0.01):

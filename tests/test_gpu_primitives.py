@@ -100,13 +100,15 @@ def test_pbs_all_messages(keys, oracle, tier, w):
     assert not dev[:, t["k"] * N: D_SMALL].any()
 
 
-def test_pbs_two_bit_rotation(gpu_ctx, oracle):
+@pytest.mark.parametrize("l,beta", [(1, 20), (3, 12)])
+def test_pbs_two_bit_rotation(gpu_ctx, oracle, l, beta):
     """tier.unroll == 2 (two key bits per blind-rotate iteration, csrc/pbs_core.h): every message decodes to f(m), the
     exported key is a bootstrapping key of the pair secret, and the device agrees with the exact-arithmetic definition
-    (oracle ref_pbs_mb2_batch) on decrypted values and on the size of the noise."""
+    (oracle ref_pbs_mb2_batch) on decrypted values and on the size of the noise.  l = 1: the paired kernel of the one-level
+    tiers; l = 3: the general form (tier T4r2: one polynomial at a time, four ciphertexts per workgroup)."""
     from dctfhe.engine import Keys, make_params
     D, w = 2048, 3
-    tier = dict(n=40, k=1, logN=11, l=1, beta=20, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52, unroll=2)
+    tier = dict(n=40, k=1, logN=11, l=l, beta=beta, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52, unroll=2)
     k = Keys(gpu_ctx, make_params(D, 40, [tier], 2.0 ** -50), seed=21)
     try:
         S, s = k.export_secret()
@@ -120,7 +122,7 @@ def test_pbs_two_bit_rotation(gpu_ctx, oracle):
         # block 3i+v of the key encrypts bit v of the pair secret: phase of the body row's gadget coefficient
         ps = oracle.pair_secret(s[:40].copy())
         assert ps.reshape(-1, 3).sum(axis=1).max() <= 1 and ps.sum() > 0
-        ref = oracle.pbs_mb2(small, bsk3, 1, 2048, 1, 20, table, w, None, D)
+        ref = oracle.pbs_mb2(small, bsk3, 1, 2048, l, beta, table, w, None, D)
         ph_dev, ph_ref = oracle.lwe_phase(S, D, dev), oracle.lwe_phase(S, D, ref)
         want = table.astype(np.uint64)
         dec = lambda ph: ((ph + (np.uint64(1) << np.uint64(63 - w - 3))) >> np.uint64(63 - w - 2)) & np.uint64((1 << (w + 2)) - 1)
