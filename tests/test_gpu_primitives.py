@@ -129,7 +129,11 @@ def test_pbs_two_bit_rotation(gpu_ctx, oracle, l, beta):
         assert np.array_equal(dec(ph_dev), f.astype(np.uint64))
         assert np.array_equal(dec(ph_ref), f.astype(np.uint64))
         err_dev, err_ref = np.abs(_centered(ph_dev - want)), np.abs(_centered(ph_ref - want))
-        assert err_dev.max() < max(4 * err_ref.max(), 2.0 ** -30), (err_dev.max(), err_ref.max())
+        # the exact-arithmetic definition carries no transform error; the device's f64 FFT does (params.var_pbs_out prices it:
+        # with three levels of 12-bit digits it dominates, sigma ~2^-25 at this n)
+        from dctfhe import params as P
+        model = P.var_pbs_out(P.TierSpec("t", n=40, k=1, logN=11, l=l, beta=beta, lk=4, betak=4, unroll=2, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52)) ** 0.5
+        assert err_dev.max() < max(4 * err_ref.max(), 2.0 ** -30, 4 * model), (err_dev.max(), err_ref.max(), model)
     finally:
         k.close()
 
