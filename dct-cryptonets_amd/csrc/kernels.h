@@ -328,13 +328,15 @@ k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
     b_src[u] = kskT + (col0 + srow + 64 * u) * (size_t)ldk + sseg;
   }
   const int fr = lane & 31, fh = (lane >> 5) * 16;
-  for (int k0 = 0; k0 < R; k0 += BK) {
-    v4i ga[2], gb[2];
+  // software pipeline: the global loads of K-step k0 + BK are issued before the matrix instructions of step k0 and land under
+  // them (round 1 loaded, waited, stored, computed: every K-step exposed a global round trip)
+  v4i ga[2], gb[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      ga[u] = *reinterpret_cast<const v4i*>(a_src[u] + k0);
-      gb[u] = *reinterpret_cast<const v4i*>(b_src[u] + k0);
-    }
+  for (int u = 0; u < 2; u++) {
+    ga[u] = *reinterpret_cast<const v4i*>(a_src[u]);
+    gb[u] = *reinterpret_cast<const v4i*>(b_src[u]);
+  }
+  for (int k0 = 0; k0 < R; k0 += BK) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -342,6 +344,13 @@ k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
       *reinterpret_cast<v4i*>(&Bs[(srow + 64 * u) * LD + sseg]) = gb[u];
     }
     __syncthreads();
+    if (k0 + BK < R) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        ga[u] = *reinterpret_cast<const v4i*>(a_src[u] + k0 + BK);
+        gb[u] = *reinterpret_cast<const v4i*>(b_src[u] + k0 + BK);
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 32) {
       v4i fa[2], fb[2];
