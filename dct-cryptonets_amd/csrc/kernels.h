@@ -293,7 +293,8 @@ __global__ void __launch_bounds__(256)
 k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R /* rows used: Deff*lk */,
           const int8_t* __restrict__ kskT, int ldk /* row stride of kskT: D*lk */, int ncol_pad, const uint64_t* __restrict__ colsum /* over the R rows used */,
           int n, int betak, uint64_t* __restrict__ out) {
-  constexpr int BM = 128, BN = 128, BK = 64, LD = BK + 16;     // +16 B per row: rows land on different bank groups
+  constexpr int BM = 128, BN = 128, BK = 128, LD = BK + 16;    // +16 B per row: rows land on different bank groups
+  constexpr int SEG = BK / 16, RPP = 256 / SEG, NU = BM / RPP;  // 16-byte segments per row, rows staged per pass, passes
   __shared__ __attribute__((aligned(16))) int8_t As[BM * LD];
   __shared__ __attribute__((aligned(16))) int8_t Bs[BN * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -316,41 +317,42 @@ k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[a][b][e] = 0;
-  // staging assignment: 2 x 16 B of A and 2 x 16 B of B per thread per K step
-  const int srow = tid >> 2, sseg = (tid & 3) * 16;
-  const uint8_t* a_src[2];
-  const int8_t* b_src[2];
+  // staging assignment: NU x 16 B of A and NU x 16 B of B per thread per K step (K step 128: half the barriers of 64; every
+  // shipped K = Deff * lk is a multiple of 128 or falls back to the remainder handling below)
+  const int srow = tid / SEG, sseg = (tid % SEG) * 16;
+  const uint8_t* a_src[NU];
+  const int8_t* b_src[NU];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    size_t c = c0 + srow + 64 * u;
+  for (int u = 0; u < NU; u++) {
+    size_t c = c0 + srow + RPP * u;
     if (c >= count) c = count - 1;
     a_src[u] = digits + c * (size_t)R + sseg;
-    b_src[u] = kskT + (col0 + srow + 64 * u) * (size_t)ldk + sseg;
+    b_src[u] = kskT + (col0 + srow + RPP * u) * (size_t)ldk + sseg;
   }
   const int fr = lane & 31, fh = (lane >> 5) * 16;
   // software pipeline: the global loads of K-step k0 + BK are issued before the matrix instructions of step k0 and land under
   // them (round 1 loaded, waited, stored, computed: every K-step exposed a global round trip)
-  v4i ga[2], gb[2];
+  // R is a multiple of 64 (checked by the host); a trailing half step reads zeros for its upper 64 bytes
+  const v4i zero4 = {0, 0, 0, 0};
+  auto fetch = [&](int k0, v4i* ga, v4i* gb) {
+    const bool live = k0 + sseg < R;
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    ga[u] = *reinterpret_cast<const v4i*>(a_src[u]);
-    gb[u] = *reinterpret_cast<const v4i*>(b_src[u]);
-  }
+    for (int u = 0; u < NU; u++) {
+      ga[u] = live ? *reinterpret_cast<const v4i*>(a_src[u] + k0) : zero4;
+      gb[u] = live ? *reinterpret_cast<const v4i*>(b_src[u] + k0) : zero4;
+    }
+  };
+  v4i ga[NU], gb[NU];
+  fetch(0, ga, gb);
   for (int k0 = 0; k0 < R; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      *reinterpret_cast<v4i*>(&As[(srow + 64 * u) * LD + sseg]) = ga[u];
-      *reinterpret_cast<v4i*>(&Bs[(srow + 64 * u) * LD + sseg]) = gb[u];
+    for (int u = 0; u < NU; u++) {
+      *reinterpret_cast<v4i*>(&As[(srow + RPP * u) * LD + sseg]) = ga[u];
+      *reinterpret_cast<v4i*>(&Bs[(srow + RPP * u) * LD + sseg]) = gb[u];
     }
     __syncthreads();
-    if (k0 + BK < R) {
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        ga[u] = *reinterpret_cast<const v4i*>(a_src[u] + k0 + BK);
-        gb[u] = *reinterpret_cast<const v4i*>(b_src[u] + k0 + BK);
-      }
-    }
+    if (k0 + BK < R) fetch(k0 + BK, ga, gb);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 32) {
       v4i fa[2], fb[2];
