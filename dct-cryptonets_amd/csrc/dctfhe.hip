@@ -772,6 +772,8 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
 static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t Lin, size_t deff, const int8_t* d_w, int Cout, int KH,
                       int KW, int stride, int pad, uint64_t* out, size_t Lout) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  // 16 output channels per thread: 32 / 64 (fewer re-reads of the input) measured 1.45x / 3.5x SLOWER -- their per-tap weights no
+  // longer fit the scalar registers (profiles/r02_exp_ablations.log)
   constexpr int COT = 16;
   dim3 grid((unsigned)((Lout + 255) / 256), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + COT - 1) / COT));
   hipLaunchKernelGGL(k_conv2d<COT>, grid, dim3(256), 0, st, in, Cin, H, W, Lin, deff, d_w, Cout, KH, KW, stride, pad, Ho, Wo, Lout, out);
