@@ -120,15 +120,43 @@ struct Op {
 };
 struct TensorShape { int32_t C, H, W, pad; };
 
+// a convolution's weights as the i8 MFMA kernel wants them: [Cout padded to 64][K padded to 32] K-contiguous, and per k the
+// input plane offset and the tap displacement (kernels.h k_conv2d_mfma)
+struct ConvPack {
+  int8_t* d_w = nullptr;
+  conv_tap* d_taps = nullptr;
+  int kpad = 0;
+  void release() { hipFree(d_w); hipFree(d_taps); d_w = nullptr; d_taps = nullptr; }
+};
+static int pack_conv(const int8_t* w, int Cout, int Cin, int H, int W, int KH, int KW, int pad, ConvPack* out) {
+  const int K = Cin * KH * KW, kpad = (K + 31) / 32 * 32, cpad = (Cout + 63) / 64 * 64;
+  std::vector<int8_t> wp((size_t)cpad * kpad, 0);
+  for (int co = 0; co < Cout; co++) memcpy(&wp[(size_t)co * kpad], w + (size_t)co * K, (size_t)K);
+  std::vector<conv_tap> tp(kpad);
+  for (int k = 0; k < kpad; k++) {
+    if (k >= K) { tp[k] = conv_tap{-1, 0, 0}; continue; }
+    const int ci = k / (KH * KW), r = k % (KH * KW);
+    tp[k] = conv_tap{ci * H * W, (int16_t)(r / KW - pad), (int16_t)(r % KW - pad)};
+  }
+  out->kpad = kpad;
+  HIPCHK(hipMalloc(&out->d_w, wp.size()));
+  HIPCHK(hipMalloc(&out->d_taps, tp.size() * sizeof(conv_tap)));
+  HIPCHK(hipMemcpy(out->d_w, wp.data(), wp.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(out->d_taps, tp.data(), tp.size() * sizeof(conv_tap), hipMemcpyHostToDevice));
+  return 0;
+}
+
 struct dctfhe_circuit {
   dctfhe_ctx* ctx = nullptr;
   std::vector<TensorShape> tensors;
   std::vector<Op> ops;
   std::vector<void*> d_payload;  // per op, device copy of its payload (weights / tables)
+  std::vector<ConvPack> conv;    // per op: the matrix-core form of a convolution's weights (empty for other ops)
   int input_tensor = 0, output_tensor = 0, max_bit_width = 0;
   ~dctfhe_circuit() {
     if (ctx) hipSetDevice(ctx->device);
     for (void* p : d_payload) if (p) hipFree(p);
+    for (ConvPack& c : conv) c.release();
   }
 };
 
@@ -769,9 +797,17 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
   return 0;
 }
 
-static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t Lin, size_t deff, const int8_t* d_w, int Cout, int KH,
-                      int KW, int stride, int pad, uint64_t* out, size_t Lout) {
+static int dev_conv2d(hipStream_t st, const uint64_t* in, int batch, int Cin, int H, int W, size_t Lin, size_t deff, const int8_t* d_w, const ConvPack* pk, int Cout,
+                      int KH, int KW, int stride, int pad, uint64_t* out, size_t Lout) {
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (pk && pk->d_w && Lout >= 32) {
+    // ciphertext rows: the contraction over (ci, ky, kx) on the matrix cores, input words split into signed byte limbs on the fly
+    dim3 grid((unsigned)((Lout + 31) / 32), (unsigned)(batch * Ho * Wo), (unsigned)((Cout + 63) / 64));
+    hipLaunchKernelGGL(k_conv2d_mfma, grid, dim3(256), 0, st, in, H, W, Lin, deff, pk->d_w, pk->d_taps, pk->kpad, Cin * H * W, Cout, stride, Ho, Wo, Lout, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // clear mode (one word per element): u64 wrap MACs on the vector ALU.
   // 16 output channels per thread: 32 / 64 (fewer re-reads of the input) measured 1.45x / 3.5x SLOWER -- their per-tap weights no
   // longer fit the scalar registers (profiles/r02_exp_ablations.log)
   constexpr int COT = 16;
@@ -941,7 +977,10 @@ extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int bat
   HIPCHK(d_w.alloc(nw));
   HIPCHK(hipMemcpy(d_in.p, in, nin * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_w.p, weight, nw, hipMemcpyHostToDevice));
-  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
+  ConvPack pk;
+  struct Rel { ConvPack& p; ~Rel() { p.release(); } } rel{pk};
+  CHK(pack_conv(weight, Cout, Cin, H, W, KH, KW, pad, &pk));
+  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), &pk, Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, d_out.p, nout * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -1063,11 +1102,16 @@ extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t siz
   HIPCHK(hipSetDevice(ctx->device));
   c->ctx = ctx;
   c->d_payload.assign(c->ops.size(), nullptr);
+  c->conv.assign(c->ops.size(), ConvPack{});
   for (size_t i = 0; i < c->ops.size(); i++) {
     const Op& o = c->ops[i];
     if (o.payload_len > 0) {
       HIPCHK(hipMalloc(&c->d_payload[i], (size_t)o.payload_len));
       HIPCHK(hipMemcpy(c->d_payload[i], (const char*)blob + o.payload_off, (size_t)o.payload_len, hipMemcpyHostToDevice));
+    }
+    if (o.type == OP_CONV) {
+      const TensorShape& a = c->tensors[o.src0];
+      CHK(pack_conv((const int8_t*)blob + o.payload_off, o.ip[0], a.C, a.H, a.W, o.ip[1], o.ip[2], o.ip[4], &c->conv[i]));
     }
   }
   *out = c.release();
@@ -1334,7 +1378,7 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
     switch (o.type) {
       case OP_CONV: {
         const int h = tm.begin(CAT_LINEAR);
-        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, Ls, ds, (const int8_t*)c->d_payload[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst, Ld));
+        CHK(dev_conv2d(st, src, B, a.C, a.H, a.W, Ls, ds, (const int8_t*)c->d_payload[i], &c->conv[i], o.ip[0], o.ip[1], o.ip[2], o.ip[3], o.ip[4], dst, Ld));
         tm.end(h);
         break;
       }

@@ -515,6 +515,97 @@ k_conv2d(const uint64_t* __restrict__ in, int Cin, int H, int W, size_t Lin, siz
   }
 }
 
+// ---- convolution on the matrix cores -------------------------------------------------------------------
+// out[co][word] = sum_k w[co][k] * in_k[word] (mod 2^64), k = (ci, ky, kx), is a GEMM with a tiny-integer left operand (|w| <= 127)
+// and a u64 right operand.  As in the key switch the u64 operand is re-expressed as 8 signed byte limbs (carries propagated),
+// here on the fly while the input tile is staged: C[co][word*8 + limb] = sum_k w[co][k] * s_limb(in_k[word]) is an i8 x i8 -> i32
+// GEMM for v_mfma_i32_32x32x32_i8 (|C| <= K * 127 * 128 < 2^31 for K <= 2^17) and out = sum_limb C_limb << 8 limb.
+// Workgroup = one output pixel x 32 ciphertext words x 64 output channels; K in steps of 32 (ci, ky, kx) triples; wave w owns
+// columns [64 w, 64 w + 64) = 8 words x 8 limbs.  Both operands K-contiguous in LDS (one ds_read_b128 per fragment).
+struct conv_tap { int32_t offset; int16_t dy, dx; };     // per k = (ci, ky, kx): ci*H*W (pixels; < 0: padding row of K), ky - pad, kx - pad
+
+__global__ void __launch_bounds__(256)
+k_conv2d_mfma(const uint64_t* __restrict__ in, int H, int W, size_t Lin, size_t Deff, const int8_t* __restrict__ wpack /* [Cout_pad64][Kpad] */,
+              const conv_tap* __restrict__ taps /* [Kpad], offset < 0: padding row */, int Kpad, int Cin_HW, int Cout, int stride, int Ho, int Wo,
+              size_t Lout, uint64_t* __restrict__ out) {
+  constexpr int BK = 32, LD = BK + 16;
+  __shared__ __attribute__((aligned(16))) int8_t As[64 * LD];
+  __shared__ __attribute__((aligned(16))) int8_t Bs[256 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pix = blockIdx.y;           // b*Ho*Wo + y*Wo + x
+  const int b = pix / (Ho * Wo), y = (pix / Wo) % Ho, x = pix % Wo;
+  const int co0 = blockIdx.z * 64;
+  // staging: thread = (word w of 32, group kq of 8): 4 consecutive k for one word
+  const int sw = tid & 31, kq = tid >> 5;
+  const size_t wg = (size_t)blockIdx.x * 32 + sw;                    // word of the output row this thread stages
+  const bool wbody = wg == Lout - 1, wlive = wbody || wg < Deff;      // (words in [Deff, Lout-1) are zero)
+  const size_t iw = wbody ? Lin - 1 : wg;
+  const uint64_t* inb = in + (size_t)b * Cin_HW * Lin;
+  const int y0 = y * stride, x0 = x * stride;
+  v16i acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[a][c][e] = 0;
+  const int fr = lane & 31, fh = (lane >> 5) * 16;
+  for (int k0 = 0; k0 < Kpad; k0 += BK) {
+    // input words of this thread's 4 taps -> signed byte limbs, limb-major so that each limb row gets one 4-byte store
+    uint32_t packed[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) packed[l] = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const conv_tap tp = taps[k0 + kq * 4 + u];
+      const int iy = y0 + tp.dy, ix = x0 + tp.dx;
+      uint64_t v = 0;
+      if (wlive && tp.offset >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = inb[((size_t)tp.offset + (size_t)(iy * W + ix)) * Lin + iw];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        int byte = (int)(v & 0xFF);
+        v >>= 8;
+        if (byte >= 128) { byte -= 256; v += 1; }
+        packed[l] |= (uint32_t)(byte & 0xFF) << (8 * u);
+      }
+    }
+    v4i ga = {0, 0, 0, 0};
+    if (tid < 128) ga = *reinterpret_cast<const v4i*>(wpack + (size_t)(co0 + (tid >> 1)) * Kpad + k0 + (tid & 1) * 16);
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 8; l++) *reinterpret_cast<uint32_t*>(&Bs[(sw * 8 + l) * LD + kq * 4]) = packed[l];
+    if (tid < 128) *reinterpret_cast<v4i*>(&As[(tid >> 1) * LD + (tid & 1) * 16]) = ga;
+    __syncthreads();
+    v4i fa[2], fb[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) fa[a] = *reinterpret_cast<const v4i*>(&As[(a * 32 + fr) * LD + fh]);
+#pragma unroll
+    for (int c = 0; c < 2; c++) fb[c] = *reinterpret_cast<const v4i*>(&Bs[(wave * 64 + c * 32 + fr) * LD + fh]);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) acc[a][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[c], acc[a][c], 0, 0, 0);
+  }
+  // epilogue: C tile layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); limb = col & 7, word = col >> 3
+  const int limb = lane & 7;
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const size_t word = (size_t)blockIdx.x * 32 + wave * 8 + c * 4 + ((lane & 31) >> 3);
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        uint64_t v = (uint64_t)(int64_t)acc[a][c][e] << (8 * limb);
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        const int co = co0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (limb == 0 && co < Cout && word < Lout) out[((((size_t)b * Cout + co) * Ho + y) * Wo + x) * Lout + word] = v;
+      }
+    }
+}
+
 // any non-zero mask word in [deff, D) of `count` ciphertexts?  (guards the effective-dimension shortcut at the session input)
 __global__ void k_tail_nonzero(const uint64_t* __restrict__ cts, size_t count, int D, int deff, int* __restrict__ flag) {
   const size_t tail = (size_t)(D - deff), total = count * tail;
