@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -126,23 +127,50 @@ struct ConvPack {
   int8_t* d_w = nullptr;
   conv_tap* d_taps = nullptr;
   int kpad = 0;
-  void release() { hipFree(d_w); hipFree(d_taps); d_w = nullptr; d_taps = nullptr; }
 };
-static int pack_conv(const int8_t* w, int Cout, int Cin, int H, int W, int KH, int KW, int pad, ConvPack* out) {
-  const int K = Cin * KH * KW, kpad = (K + 31) / 32 * 32, cpad = (Cout + 63) / 64 * 64;
-  std::vector<int8_t> wp((size_t)cpad * kpad, 0);
-  for (int co = 0; co < Cout; co++) memcpy(&wp[(size_t)co * kpad], w + (size_t)co * K, (size_t)K);
-  std::vector<conv_tap> tp(kpad);
+static void conv_pack_sizes(int Cout, int Cin, int KH, int KW, size_t* wbytes, size_t* tbytes, int* kpad) {
+  const int K = Cin * KH * KW;
+  *kpad = (K + 31) / 32 * 32;
+  *wbytes = ((size_t)((Cout + 63) / 64 * 64) * *kpad + 255) / 256 * 256;
+  *tbytes = ((size_t)*kpad * sizeof(conv_tap) + 255) / 256 * 256;
+}
+// fills host images of the packed weights / tap table (sizes from conv_pack_sizes)
+static void pack_conv_host(const int8_t* w, int Cout, int Cin, int H, int W, int KH, int KW, int pad, int kpad, int8_t* wp, conv_tap* tp) {
+  const int K = Cin * KH * KW;
+  for (int co = 0; co < Cout; co++) memcpy(wp + (size_t)co * kpad, w + (size_t)co * K, (size_t)K);
   for (int k = 0; k < kpad; k++) {
     if (k >= K) { tp[k] = conv_tap{-1, 0, 0}; continue; }
     const int ci = k / (KH * KW), r = k % (KH * KW);
     tp[k] = conv_tap{ci * H * W, (int16_t)(r / KW - pad), (int16_t)(r % KW - pad)};
   }
-  out->kpad = kpad;
-  HIPCHK(hipMalloc(&out->d_w, wp.size()));
-  HIPCHK(hipMalloc(&out->d_taps, tp.size() * sizeof(conv_tap)));
-  HIPCHK(hipMemcpy(out->d_w, wp.data(), wp.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(out->d_taps, tp.data(), tp.size() * sizeof(conv_tap), hipMemcpyHostToDevice));
+}
+// every pack of a circuit (or the single one of the dctfhe_conv2d primitive) lives in ONE device allocation: a few dozen small
+// hipMallocs ahead of key generation measurably moved the big key buffers to a placement on which the N = 8192 bootstrap ran 6 % slower
+// (profiles/r02_exp_ablations.log)
+struct ConvSlab {
+  void* d = nullptr;
+  ~ConvSlab() { hipFree(d); }
+};
+static int build_conv_packs(const std::vector<const int8_t*>& w, const std::vector<std::array<int, 7>>& g /* Cout,Cin,H,W,KH,KW,pad */, ConvSlab* slab,
+                            std::vector<ConvPack>* out) {
+  size_t total = 0;
+  std::vector<size_t> off_w(w.size()), off_t(w.size());
+  out->assign(w.size(), ConvPack{});
+  for (size_t i = 0; i < w.size(); i++) {
+    if (!w[i]) continue;
+    size_t wb, tb;
+    conv_pack_sizes(g[i][0], g[i][1], g[i][4], g[i][5], &wb, &tb, &(*out)[i].kpad);
+    off_w[i] = total; total += wb;
+    off_t[i] = total; total += tb;
+  }
+  if (!total) return 0;
+  std::vector<char> host(total, 0);
+  for (size_t i = 0; i < w.size(); i++)
+    if (w[i]) pack_conv_host(w[i], g[i][0], g[i][1], g[i][2], g[i][3], g[i][4], g[i][5], g[i][6], (*out)[i].kpad, (int8_t*)&host[off_w[i]], (conv_tap*)&host[off_t[i]]);
+  HIPCHK(hipMalloc(&slab->d, total));
+  HIPCHK(hipMemcpy(slab->d, host.data(), total, hipMemcpyHostToDevice));
+  for (size_t i = 0; i < w.size(); i++)
+    if (w[i]) { (*out)[i].d_w = (int8_t*)slab->d + off_w[i]; (*out)[i].d_taps = (conv_tap*)((char*)slab->d + off_t[i]); }
   return 0;
 }
 
@@ -152,11 +180,13 @@ struct dctfhe_circuit {
   std::vector<Op> ops;
   std::vector<void*> d_payload;  // per op, device copy of its payload (weights / tables)
   std::vector<ConvPack> conv;    // per op: the matrix-core form of a convolution's weights (empty for other ops)
+  ConvSlab conv_slab;            // ... all of them in one allocation, made when the first encrypted session is created
+  std::vector<std::vector<int8_t>> conv_w;          // host copies of the convolution weights until then
+  std::vector<std::array<int, 7>> conv_geom;
   int input_tensor = 0, output_tensor = 0, max_bit_width = 0;
   ~dctfhe_circuit() {
     if (ctx) hipSetDevice(ctx->device);
     for (void* p : d_payload) if (p) hipFree(p);
-    for (ConvPack& c : conv) c.release();
   }
 };
 
@@ -977,10 +1007,10 @@ extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int bat
   HIPCHK(d_w.alloc(nw));
   HIPCHK(hipMemcpy(d_in.p, in, nin * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_w.p, weight, nw, hipMemcpyHostToDevice));
-  ConvPack pk;
-  struct Rel { ConvPack& p; ~Rel() { p.release(); } } rel{pk};
-  CHK(pack_conv(weight, Cout, Cin, H, W, KH, KW, pad, &pk));
-  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), &pk, Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
+  ConvSlab slab;
+  std::vector<ConvPack> pk;
+  CHK(build_conv_packs({weight}, {{Cout, Cin, H, W, KH, KW, pad}}, &slab, &pk));
+  CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), &pk[0], Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, d_out.p, nout * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -1102,7 +1132,8 @@ extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t siz
   HIPCHK(hipSetDevice(ctx->device));
   c->ctx = ctx;
   c->d_payload.assign(c->ops.size(), nullptr);
-  c->conv.assign(c->ops.size(), ConvPack{});
+  std::vector<const int8_t*> cw(c->ops.size(), nullptr);
+  std::vector<std::array<int, 7>> cg(c->ops.size());
   for (size_t i = 0; i < c->ops.size(); i++) {
     const Op& o = c->ops[i];
     if (o.payload_len > 0) {
@@ -1111,9 +1142,15 @@ extern "C" int dctfhe_circuit_load(dctfhe_ctx* ctx, const void* blob, size_t siz
     }
     if (o.type == OP_CONV) {
       const TensorShape& a = c->tensors[o.src0];
-      CHK(pack_conv((const int8_t*)blob + o.payload_off, o.ip[0], a.C, a.H, a.W, o.ip[1], o.ip[2], o.ip[4], &c->conv[i]));
+      cw[i] = (const int8_t*)blob + o.payload_off;
+      cg[i] = {o.ip[0], a.C, a.H, a.W, o.ip[1], o.ip[2], o.ip[4]};
     }
   }
+  c->conv.assign(c->ops.size(), ConvPack{});
+  c->conv_w.resize(c->ops.size());
+  for (size_t i = 0; i < c->ops.size(); i++)
+    if (cw[i]) c->conv_w[i].assign(cw[i], cw[i] + c->ops[i].payload_len);
+  c->conv_geom = cg;
   *out = c.release();
   return 0;
 }
@@ -1197,6 +1234,15 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
       if (w > keys->p.tiers[tt].logN - 1) return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt);
       if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) return fail("op %zu names a coarse bit tier the keys lack", i);
     }
+  if (keys && !circ->conv_slab.d) {
+    // the matrix-core form of the convolution weights, once per circuit and only for encrypted evaluation; allocated here, after the
+    // keys, not at circuit load: device allocations made before key generation moved the key buffers to a placement on which the
+    // N = 8192 bootstrap measured 5 % slower (same box, same binary: profiles/r02_exp_ablations.log)
+    std::vector<const int8_t*> cw(circ->ops.size(), nullptr);
+    for (size_t i = 0; i < circ->ops.size(); i++)
+      if (i < circ->conv_w.size() && !circ->conv_w[i].empty()) cw[i] = circ->conv_w[i].data();
+    CHK(build_conv_packs(cw, circ->conv_geom, &circ->conv_slab, &circ->conv));
+  }
   // tensor liveness: free a buffer after its last reader; reuse freed buffers of sufficient size
   const int nt = (int)circ->tensors.size();
   std::vector<int> last_use(nt, -1);
