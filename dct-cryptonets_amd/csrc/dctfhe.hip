@@ -144,9 +144,7 @@ static void pack_conv_host(const int8_t* w, int Cout, int Cin, int H, int W, int
     tp[k] = conv_tap{ci * H * W, (int16_t)(r / KW - pad), (int16_t)(r % KW - pad)};
   }
 }
-// every pack of a circuit (or the single one of the dctfhe_conv2d primitive) lives in ONE device allocation: a few dozen small
-// hipMallocs ahead of key generation measurably moved the big key buffers to a placement on which the N = 8192 bootstrap ran 6 % slower
-// (profiles/r02_exp_ablations.log)
+// every pack of a circuit (or the single one of the dctfhe_conv2d primitive) lives in ONE device allocation
 struct ConvSlab {
   void* d = nullptr;
   ~ConvSlab() { hipFree(d); }
@@ -517,7 +515,11 @@ static int eval_alloc(dctfhe_ctx* ctx, const dctfhe_params* params, std::unique_
       const long double PI = 3.141592653589793238462643383279502884L;
       for (int m = 0; m < 2 * N; m++) { const long double a = PI * m / N; wt[m] = cmk((double)cosl(a), (double)sinl(a)); }
       for (int m = 0; m < 8; m++) wt[(size_t)2 * N + m] = root64(8 * m);
-      HIPCHK(hipMalloc(&tk.d_wtab, wt.size() * sizeof(cplx)));
+      // the root table is gathered from at random by every thread of the two-bit kernels, every iteration: give it an allocation that
+      // maps with one large page (a 262 KB allocation lands wherever the sub-allocator has room, and the N = 8192 bootstrap measured
+      // 0 / +4 / +5 / +11 % at table addresses that were 256 / 64 / 128 / 32 KB-aligned: profiles/r02_exp_ablations.log)
+      const size_t wt_bytes = (((wt.size() * sizeof(cplx)) + (2u << 20) - 1) >> 21) << 21;
+      HIPCHK(hipMalloc(&tk.d_wtab, wt_bytes));
       HIPCHK(hipMemcpyAsync(tk.d_wtab, wt.data(), wt.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
     }
@@ -1235,9 +1237,8 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
       if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) return fail("op %zu names a coarse bit tier the keys lack", i);
     }
   if (keys && !circ->conv_slab.d) {
-    // the matrix-core form of the convolution weights, once per circuit and only for encrypted evaluation; allocated here, after the
-    // keys, not at circuit load: device allocations made before key generation moved the key buffers to a placement on which the
-    // N = 8192 bootstrap measured 5 % slower (same box, same binary: profiles/r02_exp_ablations.log)
+    // the matrix-core form of the convolution weights, once per circuit and only for encrypted evaluation (clear mode runs the VALU
+    // kernel), in one allocation
     std::vector<const int8_t*> cw(circ->ops.size(), nullptr);
     for (size_t i = 0; i < circ->ops.size(); i++)
       if (i < circ->conv_w.size() && !circ->conv_w[i].empty()) cw[i] = circ->conv_w[i].data();
