@@ -427,6 +427,10 @@ pbs_kernel(pbs_launch a) {
   cplx* tw = reinterpret_cast<cplx*>(smem_raw);
   unsigned char* per_group = smem_raw + G::TW_BYTES;
   for (int x = threadIdx.x; x < G::TW_LDS_ELEMS; x += blockDim.x) tw[x] = a.tw[x];
+  if constexpr (MB) {     // root tables of the two-bit rotation: lo[j] = zeta^j, hi[j] = zeta^(j << ZLO)
+    cplx* zl = tw + G::TW_LDS_ELEMS;
+    for (int x = threadIdx.x; x < G::ZLUT_ELEMS; x += blockDim.x) zl[x] = x < (1 << G::ZLO) ? a.wtab[x] : a.wtab[(size_t)(x - (1 << G::ZLO)) << G::ZLO];
+  }
   __syncthreads();
 #if defined(DCTFHE_STAGGER)   // experiment: desynchronise co-resident workgroups by half a transform
   if ((blockIdx.x >> 8) & 1) for (int z = 0; z < DCTFHE_STAGGER; z++) __builtin_amdgcn_s_sleep(64);
@@ -454,6 +458,7 @@ pbs_kernel(pbs_launch a) {
   A.bsk_wrap = a.bsk_wrap;
   A.pf_parts = a.pf_parts;
   A.wtab = a.wtab;
+  A.zlut = MB ? tw + G::TW_LDS_ELEMS : nullptr;
   if constexpr (G::TWIST_LDS) A.twist = tw + G::F::TW_TOTAL; else A.twist = a.tw + G::F::TW_TOTAL;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
 #if defined(DCTFHE_ABLATE_BARRIER)   // timing experiments only (tools/exp_pbs.hip): no workgroup barriers, wrong results

@@ -109,7 +109,12 @@ struct pbs_geom {
   // LDS and leave the T twist bases in global memory (read once per bootstrap)
   static constexpr bool TWIST_LDS = !(PAIR && LOGN >= 12);
   static constexpr int TW_LDS_ELEMS = TWIST_LDS ? F::TW_ELEMS : F::TW_TOTAL;
-  static constexpr int TW_BYTES = TW_LDS_ELEMS * 16;
+  // two-bit kernels: zeta^m = e^{i pi m / N}, m < 2N, as the product of two small LDS tables (m = hi * 2^ZLO + lo) instead of a gather
+  // from a 2N-entry table in global memory: the general form needs 8 * NG monomial factors per gadget row (48 random 16-byte
+  // gathers per iteration at N = 2048), and the vector memory path, not the ALU, is what those kernels wait for
+  static constexpr int ZLO = MB ? (LOGN + 2) / 2 : 0, ZHI = MB ? LOGN + 1 - ZLO : 0;
+  static constexpr int ZLUT_ELEMS = MB ? (1 << ZLO) + (1 << ZHI) : 0;
+  static constexpr int TW_BYTES = (TW_LDS_ELEMS + ZLUT_ELEMS) * 16;
 };
 
 // signed gadget decomposition, closest-representable rounding; digs[lev], lev 0 most significant, digits in [-B/2, B/2).
@@ -199,6 +204,7 @@ struct pbs_args {
   uint64_t body_add;          // added to the body word (accumulate mode: the "- v" of a bit step)
   int bsk_wrap;               // 0 = off; >0: key bit i reads BSK[i % bsk_wrap] (cache experiments only)
   const cplx* wtab;           // MB: e^{i pi m / N}, m < 2N (monomials in the Fourier domain), then e^{2 pi i k / 8}, k < 8
+  const cplx* zlut;           // MB, device: the same roots as two LDS tables, lo[2^ZLO] then hi[2^ZHI] (nullptr: gather from wtab)
   const cplx* twist;          // the T twist bases e^{i pi t/N} (entries TW_TOTAL.. of the twiddle table; LDS or global)
   int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
 };
@@ -271,6 +277,16 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
     });
   }
 
+  // zeta^m: on the device the product of the two LDS tables, on the host emulator (zlut == nullptr) the full table
+  auto zeta = [&](uint32_t m) -> cplx {
+#if defined(DCTFHE_DEVICE) && !defined(DCTFHE_NO_ZLUT)      // (DCTFHE_NO_ZLUT: timing experiments, tools/exp_pbs.hip)
+    return cmul(A.zlut[(1 << G::ZLO) + (m >> G::ZLO)], A.zlut[m & ((1u << G::ZLO) - 1)]);
+#elif defined(DCTFHE_DEVICE)
+    return A.wtab[m];
+#else
+    return A.zlut ? cmul(A.zlut[(1 << G::ZLO) + (m >> G::ZLO)], A.zlut[m & ((1u << G::ZLO) - 1)]) : A.wtab[m];
+#endif
+  };
   for (int i = 0; i < n; i += (MB ? 2 : 1)) {
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = make_uniform(A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT);
@@ -314,8 +330,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             constexpr int j = decltype(J)::value;
             constexpr int g = j / G::RL, jp = j % G::RL;
             if constexpr (jp == 0) {
-              zb1 = A.wtab[(a * ulow[g]) & (2 * N - 1)];
-              zb2 = A.wtab[(a2 * ulow[g]) & (2 * N - 1)];
+              zb1 = zeta((a * ulow[g]) & (2 * N - 1));
+              zb2 = zeta((a2 * ulow[g]) & (2 * N - 1));
             }
             cplx z1 = zb1, z2 = zb2;
             if constexpr (jp > 0) {
@@ -370,8 +386,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
         constexpr int j = decltype(J)::value;
         constexpr int g = j / G::RL, jp = j % G::RL;
         if constexpr (jp == 0) {
-          zb1 = A.wtab[(a * ulow[g]) & (2 * N - 1)];
-          zb2 = A.wtab[(a2 * ulow[g]) & (2 * N - 1)];
+          zb1 = zeta((a * ulow[g]) & (2 * N - 1));
+          zb2 = zeta((a2 * ulow[g]) & (2 * N - 1));
         }
         cplx z1 = zb1, z2 = zb2;
         if constexpr (jp > 0) {

@@ -52,6 +52,11 @@ static int run_case(int n_in, int beta, int w, double sigma_bsk) {
   std::vector<cplx> wtab(2 * N + 8);
   for (int m = 0; m < 2 * N; m++) { const long double a = 3.141592653589793238462643383279502884L * m / N; wtab[m] = cmk((double)cosl(a), (double)sinl(a)); }
   for (int m = 0; m < 8; m++) wtab[2 * N + m] = root64(8 * m);
+  std::vector<cplx> zlut;      // the device's two-table form of the same roots (pbs_geom::ZLO / ZHI)
+  if (MB) {
+    for (int j = 0; j < (1 << G::ZLO); j++) zlut.push_back(wtab[j]);
+    for (int j = 0; j < (1 << G::ZHI); j++) zlut.push_back(wtab[(size_t)j << G::ZLO]);
+  }
   std::vector<unsigned char> shared(G::SHARED_BYTES);   // rotation stage aliases the exchange buffer, as on the device
   std::vector<uint64_t> accl((size_t)G::NL * N + 1);
   std::vector<uint32_t> pfd(T);
@@ -68,7 +73,7 @@ static int run_case(int n_in, int beta, int w, double sigma_bsk) {
         pbs_args A;
         A.ct_small = cts.data() + (size_t)c * (n_in + 1); A.n = n_in; A.wtab = wtab.data(); A.beta = beta; A.bsk = bsk_dev.data();
         A.table = table.data(); A.w = w; A.out = emu_out.data() + (size_t)c * (D + 1); A.D_out = D;
-        A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = 0;
+        A.accumulate = 0; A.body_add = 0; A.bsk_wrap = 0; A.pf_parts = 0; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = 0; A.zlut = zlut.empty() ? nullptr : zlut.data();
         pbs_thread<LOGN, K, L, P, MB>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
         sync();
       }
@@ -267,7 +272,7 @@ static int pf_guard_case(int n_in, int wrap, int pf_parts) {
       pbs_args A;
       A.ct_small = ct.data(); A.n = n_in; A.wtab = wtab.data(); A.beta = L == 1 ? 20 : 10; A.bsk = bsk_dev;
       A.table = table.data(); A.w = 4; A.out = out.data(); A.D_out = D;
-      A.accumulate = 0; A.body_add = 0; A.bsk_wrap = wrap; A.pf_parts = pf_parts; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = pf_rank;
+      A.accumulate = 0; A.body_add = 0; A.bsk_wrap = wrap; A.pf_parts = pf_parts; A.twist = tw.data() + G::F::TW_TOTAL; A.pf_rank = pf_rank; A.zlut = nullptr;
       pbs_thread<LOGN, K, L, P, MB>(A, t, tw.data(), reinterpret_cast<uint64_t*>(shared.data() + G::STAGE_OFFSET), reinterpret_cast<cplx*>(shared.data()), accl.data(), pfd.data(), sync, sync);
     };
     std::vector<std::thread> th;
