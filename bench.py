@@ -39,7 +39,7 @@ FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not 
 
 # VALU instructions per blind-rotate loop iteration and wave, and waves per ciphertext, of the bootstrap kernels (ISA listing of the
 # shipped build: hipcc -S + tools/isa_hist.py).  key: (logN, k, l, unroll).  An iteration consumes `unroll` key bits.
-VALU_PER_ITERATION = {(13, 1, 1, 2): (2419, 8), (12, 1, 1, 2): (2337, 4), (11, 1, 1, 2): (2300, 2), (11, 1, 3, 1): (4511, 2), (11, 1, 3, 2): (5955, 2), (10, 2, 1, 1): (2798, 1)}
+VALU_PER_ITERATION = {(13, 1, 1, 2): (2419, 8), (12, 1, 1, 2): (2337, 4), (11, 1, 1, 2): (2300, 2), (11, 1, 3, 1): (4511, 2), (11, 1, 3, 2): (5955, 2), (10, 2, 1, 1): (2798, 1), (10, 2, 1, 2): (3802, 1)}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4          # wave-instructions per second: 256 CUs x 4 SIMDs, one f64 wave instruction per 4 cycles, 2.4 GHz
 
 

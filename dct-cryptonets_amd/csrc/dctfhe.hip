@@ -312,6 +312,21 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
     HIPCHK(hipGetLastError());
     return 0;
   }
+  if (t.logN == 10 && t.k == 2 && t.l == 1 && t.unroll == 2) {
+    // general two-bit rotation for the one-level bit tier (Ba2): one wave per ciphertext, four per workgroup
+    using G = pbs_geom<10, 2, 1, 8, 1>;
+    constexpr int GR = 4;
+    const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<10, 2, 1, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+    const unsigned grid = (unsigned)((a.count + GR - 1) / GR);
+    hipLaunchKernelGGL((pbs_kernel<10, 2, 1, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   return fail("no bootstrap kernel instantiated for logN=%d k=%d l=%d unroll=%d", t.logN, t.k, t.l, t.unroll);
 }
 
@@ -392,8 +407,12 @@ static int check_params(const dctfhe_params* p) {
     if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 28))
       return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 28 when l == 1: 32-bit accumulators)", i);
     if (t.unroll != 1 && t.unroll != 2) return fail("tier %d: unroll must be 1 or 2", i);
-    if (t.unroll == 2 && (t.k != 1 || !(t.l == 1 || (t.l == 3 && t.logN == 11)) || t.logN < 11 || (t.n & 1)))
-      return fail("tier %d: unroll 2 needs k = 1, n even and l = 1 with N >= 2048, or l = 3 with N = 2048", i);
+    if (t.unroll == 2) {
+      const bool paired = t.k == 1 && t.l == 1 && t.logN >= 11;                                        // pair-interleaved kernels
+      const bool general = (t.k == 1 && t.l == 3 && t.logN == 11) || (t.k == 2 && t.l == 1 && t.logN == 10);   // general form
+      if (!(paired || general) || (t.n & 1))
+        return fail("tier %d: unroll 2 needs n even and (k, l, N) = (1, 1, >= 2048), (1, 3, 2048) or (2, 1, 1024)", i);
+    }
     if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);
@@ -853,18 +872,29 @@ static unsigned ew_grid(size_t n) { return (unsigned)std::max<size_t>(1, std::mi
 
 // exact rounding + table look-up on `count` ciphertexts, in place on d_work (already shifted / offset)
 struct LutScratch { uint8_t* digits = nullptr; uint64_t* bodies = nullptr; uint64_t* small = nullptr; int64_t* bit_tables = nullptr; size_t chunk = 0; };
-// rounding steps i >= coarse_from run on bit_tier_coarse (a one-level twin of bit_tier; the compiler proves it is safe).
+// Tier of rounding step i of a look-up op: ip[5] (bit tier), from step ip[8] on its one-level twin ip[7], from step ip[11] & 255 on the
+// two-bit-rotation twin ip[11] >> 8 (the compiler proves each hand-over safe; dctfhe/compile.py::step_tier is the same rule).
+struct StepTiers {
+  int bit = -1, coarse = -1, coarse_from = 1 << 30, coarse2 = -1, coarse2_from = 1 << 30;
+  int at(int i) const { return (coarse2 >= 0 && i >= coarse2_from) ? coarse2 : (coarse >= 0 && i >= coarse_from) ? coarse : bit; }
+};
+static StepTiers step_tiers_of(const Op& o) {
+  StepTiers s;
+  s.bit = o.ip[5]; s.coarse = o.ip[7]; s.coarse_from = o.ip[8];
+  if (o.ip[11] >= 0) { s.coarse2 = o.ip[11] >> 8; s.coarse2_from = o.ip[11] & 255; }
+  return s;
+}
 // r > 0: in place on d_work (rows of Lw words, already shifted / offset; the first `deff` mask words may be non-zero).
 // r == 0: nothing modifies the input, so the key switch reads d_src (rows of Ls words) directly with the site's shift and
 // body offset applied on the fly, and the table bootstrap writes d_work -- no copy of the tensor at all.
-static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int coarse_from, int tab_tier, const uint64_t* d_src, size_t Ls, int shift,
+static int dev_round_lut(dctfhe_keys* K, const StepTiers& stp, int tab_tier, const uint64_t* d_src, size_t Ls, int shift,
                          uint64_t body_add, uint64_t* d_work, size_t Lw, size_t count, int p, int r, const int64_t* d_tables, int w, const int32_t* d_idx,
                          int hw, int nchan, const LutScratch& sc, Timers* tm, int deff = 0) {
   for (size_t c0 = 0; c0 < count; c0 += sc.chunk) {
     const size_t cn = std::min(sc.chunk, count - c0);
     uint64_t* w0 = d_work + c0 * Lw;
     for (int i = 0; i < r; i++) {
-      const int bt = (bit_tier_coarse >= 0 && i >= coarse_from) ? bit_tier_coarse : bit_tier;
+      const int bt = stp.at(i);
       CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm, deff, Lw));
       const int vlog = 62 - p + i;
       CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm, Lw));
@@ -876,10 +906,12 @@ static int dev_round_lut(dctfhe_keys* K, int bit_tier, int bit_tier_coarse, int 
   return 0;
 }
 // the mask words a rounding chain touches: its input's, and the rings of the bit tiers whose outputs it accumulates
-static int round_chain_deff(const dctfhe_keys* K, int src_deff, int bit_tier, int bit_tier_coarse, int coarse_from, int r) {
-  auto ring = [&](int tier) { return tier >= 0 ? (K->p.tiers[tier].k << K->p.tiers[tier].logN) : 0; };
+static int round_chain_deff(const dctfhe_keys* K, int src_deff, const StepTiers& stp, int r) {
   int d = src_deff;
-  if (r > 0) d = std::max(d, std::max(coarse_from > 0 ? ring(bit_tier) : 0, coarse_from < r ? ring(bit_tier_coarse) : 0));
+  for (int i = 0; i < r; i++) {
+    const int tier = stp.at(i);
+    if (tier >= 0) d = std::max(d, K->p.tiers[tier].k << K->p.tiers[tier].logN);
+  }
   return d;
 }
 
@@ -987,7 +1019,9 @@ extern "C" int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int bit_ti
                        1ULL << (63 - p + r - 1));
     HIPCHK(hipGetLastError());
   }
-  CHK(dev_round_lut(K, bit_tier, -1, r, tab_tier, d_work.as<uint64_t>(), L, 0, 0, d_work.as<uint64_t>(), L, count, p, r, d_tab.as<int64_t>(), w,
+  StepTiers stp;
+  stp.bit = bit_tier;
+  CHK(dev_round_lut(K, stp, tab_tier, d_work.as<uint64_t>(), L, 0, 0, d_work.as<uint64_t>(), L, count, p, r, d_tab.as<int64_t>(), w,
                     d_idx.as<int32_t>(), 1, 1, sc.s, nullptr));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(cts_out, d_work.p, count * L * 8, hipMemcpyDeviceToHost));
@@ -1204,8 +1238,9 @@ extern "C" int dctfhe_circuit_stats(dctfhe_circuit* c, const dctfhe_params* P, d
           s->flops_f64 += ein * tier_flops(P->tiers[tt]);
           s->key_bytes_per_pass += key_bytes(P->tiers[tt]);
         }
+        const StepTiers stp = step_tiers_of(o);
         for (int st = 0; st < r; st++) {
-          const int b2 = (o.ip[7] >= 0 && st >= o.ip[8]) ? o.ip[7] : bt;
+          const int b2 = stp.at(st);
           if (b2 < 0 || b2 >= P->n_tiers) continue;
           s->pbs_count[b2] += (int64_t)ein; s->ks_count[b2] += (int64_t)ein;
           s->flops_f64 += ein * tier_flops(P->tiers[b2]);
@@ -1234,7 +1269,9 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
       const int tt = o.ip[4], bt = o.ip[5], r = o.ip[9] ? 0 : o.ip[1], w = o.ip[2];
       if (tt < 0 || tt >= keys->p.n_tiers || (r > 0 && (bt < 0 || bt >= keys->p.n_tiers))) return fail("op %zu names a tier the keys lack", i);
       if (w > keys->p.tiers[tt].logN - 1) return fail("op %zu: table of 2^%d entries does not fit tier %d", i, w, tt);
-      if (r > 0 && o.ip[8] < r && (o.ip[7] < 0 || o.ip[7] >= keys->p.n_tiers)) return fail("op %zu names a coarse bit tier the keys lack", i);
+      const StepTiers stp = step_tiers_of(o);
+      for (int st = 0; st < r; st++)
+        if (stp.at(st) < 0 || stp.at(st) >= keys->p.n_tiers) return fail("op %zu names a coarse bit tier the keys lack", i);
     }
   if (keys && !circ->conv_slab.d) {
     // the matrix-core form of the convolution weights, once per circuit and only for encrypted evaluation (clear mode runs the VALU
@@ -1279,7 +1316,7 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
         const int r = o.ip[9] ? 0 : o.ip[1], tt = o.ip[4];
         const size_t ring = (size_t)keys->p.tiers[tt].k << keys->p.tiers[tt].logN;
         if (clampd(o.ip[10]) < s->t_deff[o.src0]) return fail("op %zu: look-up compiled for effective dimension %d, its input has %zu", i, o.ip[10], s->t_deff[o.src0]);
-        const size_t chain = r > 0 ? (size_t)round_chain_deff(keys, (int)clampd(o.ip[10]), o.ip[5], o.ip[7], o.ip[8], r) : 0;
+        const size_t chain = r > 0 ? (size_t)round_chain_deff(keys, (int)clampd(o.ip[10]), step_tiers_of(o), r) : 0;
         set(o.dst, ring, chain);
       } else if (o.type == OP_ADD) {
         set(o.dst, std::max(s->t_deff[o.src0], s->t_deff[o.src1]), 0);
@@ -1467,13 +1504,13 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
           const uint64_t add = body_add + (approx ? (1ULL << (62 - p)) : (r > 0 ? (1ULL << (63 - p + r - 1)) : 0));
           int deff = (int)ds;
           if (steps > 0) {
-            deff = round_chain_deff(K, (int)ds, bt, o.ip[7], o.ip[8], steps);
+            deff = round_chain_deff(K, (int)ds, step_tiers_of(o), steps);
             const int h = tm.begin(CAT_LINEAR);
             hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * ((size_t)deff + 1))), dim3(256), 0, st, src, Ls, ds, dst, Ld, E, (size_t)deff, shift, add);
             HIPCHK(hipGetLastError());
             tm.end(h);
           }
-          CHK(dev_round_lut(K, bt, o.ip[7], o.ip[8], tt, src, Ls, shift, add, dst, Ld, E, p, steps, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm, deff));
+          CHK(dev_round_lut(K, step_tiers_of(o), tt, src, Ls, shift, add, dst, Ld, E, p, steps, (const int64_t*)c->d_payload[i], w, nullptr, hw, nchan, sc, &tm, deff));
         }
         break;
       }

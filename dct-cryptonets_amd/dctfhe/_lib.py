@@ -11,7 +11,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PKG_DIR, "libdctfhe.so")
-MAX_TIERS = 8
+MAX_TIERS = 12
 
 
 class Tier(C.Structure):

@@ -100,6 +100,7 @@ class OpInfo:
     note: str = ""
     pfail: float = 0.0
     coarse_from: int = -1             # rounding steps i >= coarse_from run on the one-level bit tier
+    coarse2_from: int = -1            # ... and steps i >= coarse2_from on the two-bit-rotation bit tier (ip[11] = tier << 8 | from)
     sim_sigma: float = 0.0            # modelled noise std at the input of the site's table bootstrap (fraction of the torus)
 
 
@@ -158,12 +159,9 @@ class CompiledCircuit:
             n = s.C * s.H * s.W
             out[ps.tiers[o.ip[4]].name] = out.get(ps.tiers[o.ip[4]].name, 0) + n
             if o.r and not o.ip[9]:
-                cf = o.ip[8] if (o.ip[7] >= 0 and o.ip[8] < o.r) else o.r
-                fine, coarse = min(cf, o.r), o.r - min(cf, o.r)
-                if fine:
-                    out[ps.tiers[o.ip[5]].name] = out.get(ps.tiers[o.ip[5]].name, 0) + n * fine
-                if coarse:
-                    out[ps.tiers[o.ip[7]].name] = out.get(ps.tiers[o.ip[7]].name, 0) + n * coarse
+                for st in range(o.r):
+                    nm = ps.tiers[step_tier(o, st)].name
+                    out[nm] = out.get(nm, 0) + n
         return out
 
     def report(self):
@@ -186,12 +184,23 @@ class CompiledCircuit:
                          f"tier={ps.tiers[o.ip[4]].name}" + (", rounding=approximate" if o.ip[9] else "") +
                          (f", bit_tier={ps.tiers[o.ip[5]].name}" if (o.r and not o.ip[9]) else "") +
                          (f", steps>={o.ip[8]}:{ps.tiers[o.ip[7]].name}" if (o.r and not o.ip[9] and o.ip[7] >= 0 and o.ip[8] < o.r) else "") +
+                         (f", steps>={o.ip[11] & 255}:{ps.tiers[o.ip[11] >> 8].name}" if (o.r and not o.ip[9] and o.ip[11] >= 0 and (o.ip[11] & 255) < o.r) else "") +
                          f", tables={o.ip[6]}, p_fail/elt={o.pfail:.1e}}}  // {o.note}")
             lines.append(f"{head} : [{s.C}x{s.H}x{s.W}] -> [{d.C}x{d.H}x{d.W}] e={d.e}")
         lines.append(f"// expected table failures per image (noise model): {self.expected_failures_per_image:.2e}")
         if self.rounding_method == "approximate":
             lines.append(f"// approximate rounding: expected boundary flips per image: {self.expected_boundary_flips_per_image:.2e}")
         return "\n".join(lines)
+
+
+def step_tier(o, i):
+    """tier index of rounding step i of look-up op `o`: bit tier, from ip[8] on the coarse twin ip[7], from ip[11] & 255 on ip[11] >> 8"""
+    t = o.ip[5]
+    if o.ip[7] >= 0 and i >= o.ip[8]:
+        t = o.ip[7]
+    if o.ip[11] >= 0 and i >= (o.ip[11] & 255):
+        t = o.ip[11] >> 8
+    return t
 
 
 class _Act:
@@ -469,6 +478,7 @@ def _assign_encodings(circ):
                 raise ValueError("table wider than the ring")
             o.ip[:7] = [o.p, o.r, o.w, shift, tier, ps.bit_tier if o.r > 0 else -1, o.table_values.shape[0]]
             o.ip[7], o.ip[8] = (ps.bit_tier_coarse if ps.bit_tier_coarse is not None else -1), o.r      # refined by _estimate_noise
+            o.ip[11] = -1
             o.ip[9] = 1 if (circ.rounding_method == "approximate" and o.r > 0) else 0
             o.ip[10] = T[o.src0].deff
             T[o.dst].deff = ps.tiers[tier].k << ps.tiers[tier].logN
@@ -505,7 +515,9 @@ def _estimate_noise(circ):
 
             approx = bool(o.ip[9])
 
-            def site_pfail(coarse_from):
+            c2 = getattr(ps, "bit_tier_coarse2", None)
+
+            def site_pfail(coarse_from, coarse2_from=None):
                 pf_, v_ = 0.0, v_in0
                 if approx:
                     # no rounding steps: the low r bits ride along; a failure is noise beyond the half-box.  (The two inputs
@@ -517,8 +529,12 @@ def _estimate_noise(circ):
                     v_bit_in = P.var_keyswitch(max(d_in, bt.k << bt.logN), bt) + P.var_modswitch(bt)
                     for i in range(o.r):
                         pf_ += P.p_fail(0.25, 4.0 ** (o.p - i) * v_ + v_bit_in)
-                        step_tier = ps.tiers[o.ip[7]] if (i >= coarse_from and o.ip[7] >= 0) else bt
-                        v_ += P.var_pbs_out(step_tier, ps.fft_noise_c)
+                        step = bt
+                        if i >= coarse_from and o.ip[7] >= 0:
+                            step = ps.tiers[o.ip[7]]
+                        if coarse2_from is not None and i >= coarse2_from:
+                            step = ps.tiers[c2]
+                        v_ += P.var_pbs_out(step, ps.fft_noise_c)
                 return pf_ + P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
 
             pf = site_pfail(o.r)
@@ -530,12 +546,19 @@ def _estimate_noise(circ):
                     cf -= 1
                 o.coarse_from = o.ip[8] = cf
                 pf = site_pfail(cf)
+                if c2 is not None:      # ... and, inside that budget, the earliest step from which the two-bit-rotation tier will do
+                    cf2 = o.r
+                    while cf2 > cf and site_pfail(cf, cf2 - 1) <= budget:
+                        cf2 -= 1
+                    o.coarse2_from = cf2
+                    o.ip[11] = (c2 << 8) | cf2 if cf2 < o.r else -1
+                    pf = site_pfail(cf, cf2 if cf2 < o.r else None)
             o.pfail = pf
             v_sim = v_in0
             if o.r > 0 and not approx:                      # what the rounding steps leave on the working ciphertext
                 bt = ps.tiers[o.ip[5]]
                 for i in range(o.r):
-                    v_sim += P.var_pbs_out(ps.tiers[o.ip[7]] if (i >= o.ip[8] and o.ip[7] >= 0) else bt, ps.fft_noise_c)
+                    v_sim += P.var_pbs_out(ps.tiers[step_tier(o, i)], ps.fft_noise_c)
             o.sim_sigma = math.sqrt(v_sim + v_tab_in)
             if approx:
                 flips += (2.0 / 2 ** o.r) * P.p_fail(2.0 ** -(o.p + 2), v_in0 + v_tab_in) * n_elt

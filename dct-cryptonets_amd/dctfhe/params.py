@@ -59,6 +59,7 @@ class ParamSet:
     coarse_tier_for_w: dict = None     # same, for tables whose output only feeds an add or the circuit output (noisier is fine)
     table_tier_fallback_for_w: dict = None   # quieter (slower) tiers the compiler falls back to when a site leaves the budget
     bit_tier_coarse: int = None        # one-level twin of the bit tier for the last rounding steps of a site
+    bit_tier_coarse2: int = None       # a still cheaper (noisier) twin for the steps after those
     refresh_min_w: int = None          # tables this wide that feed a convolution are split: coarse look-up + small-ring refresh
     p_budget: float = 1e-12            # failure probability a single look-up site may spend on cheaper rounding steps
     input_sigma: float = 0.0
@@ -155,8 +156,12 @@ def default_params():
     # T5a: one-level twin of the three-level 5-bit tier; the 5-bit residual-sum table is split the same way (T5a + T4r)
     t5a = TierSpec("T5a", n=832, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
     # (a table of 5 or 6 input bits that feeds a convolution without the split would run on T6; with refresh_min_w = 5 none does)
-    return ParamSet(D=8192, tiers=[t6, t4r, t4, b, t6a, ba, t4r2, t5a], bit_tier=3, table_tier_for_w={4: 6, 6: 0},
-                    table_tier_fallback_for_w={4: 1}, coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, refresh_min_w=5, input_dim=2048)
+    # Ba2: the one-level bit tier on the general two-bit rotation: 49.7 ms per launch of 16 384 against 63.6 (profiles/r02_exp_ablations.log),
+    # output 0.5 bit noisier (2^-14.5): the compiler gives it the steps of a chain that can take that (78 % of them), Ba the ones before.
+    ba2 = TierSpec("Ba2", n=584, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3, unroll=2)
+    return ParamSet(D=8192, tiers=[t6, t4r, t4, b, t6a, ba, t4r2, t5a, ba2], bit_tier=3, table_tier_for_w={4: 6, 6: 0},
+                    table_tier_fallback_for_w={4: 1}, coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, bit_tier_coarse2=8, refresh_min_w=5,
+                    input_dim=2048)
 
 
 def params_for_p_error(p_error=0.01):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DCTFHE_MAX_TIERS 8
+#define DCTFHE_MAX_TIERS 12
 
 typedef struct dctfhe_ctx dctfhe_ctx;
 typedef struct dctfhe_client_key dctfhe_client_key;   /* CLIENT: secret keys + the CSPRNG keys; never needed by the server */

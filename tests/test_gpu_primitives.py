@@ -100,6 +100,30 @@ def test_pbs_all_messages(keys, oracle, tier, w):
     assert not dev[:, t["k"] * N: D_SMALL].any()
 
 
+def test_pbs_two_bit_rotation_k2(gpu_ctx, oracle):
+    """the general two-bit rotation on k = 2, N = 1024, one level (tier Ba2: one wave per ciphertext) against its definition"""
+    from dctfhe.engine import Keys, make_params
+    D, w, N = 2048, 3, 1024
+    tier = dict(n=40, k=2, logN=10, l=1, beta=20, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52, unroll=2)
+    k = Keys(gpu_ctx, make_params(D, 40, [tier], 2.0 ** -50), seed=23)
+    try:
+        S, s = k.export_secret()
+        msgs = np.arange(1 << w, dtype=np.uint64)
+        small = oracle.lwe_encrypt(s[:40].copy(), 40, msgs << np.uint64(63 - w), 2.0 ** -30, seed=14)
+        f = (msgs * 5 + 2) % (1 << w)
+        table = f.astype(np.int64) << (63 - w - 2)
+        dev = k.pbs(0, np.concatenate([small, small, small]), table, w)[: 1 << w]          # 24 ciphertexts: partial workgroups too
+        ref = oracle.pbs_mb2(small, k.export_bsk(0), 2, N, 1, 20, table, w, None, D)
+        ph_dev, ph_ref = oracle.lwe_phase(S, D, dev), oracle.lwe_phase(S, D, ref)
+        dec = lambda ph: ((ph + (np.uint64(1) << np.uint64(63 - w - 3))) >> np.uint64(63 - w - 2)) & np.uint64((1 << (w + 2)) - 1)
+        assert np.array_equal(dec(ph_dev), f.astype(np.uint64)) and np.array_equal(dec(ph_ref), f.astype(np.uint64))
+        want = table.astype(np.uint64)
+        err_dev, err_ref = np.abs(_centered(ph_dev - want)), np.abs(_centered(ph_ref - want))
+        assert err_dev.max() < max(4 * err_ref.max(), 2.0 ** -30), (err_dev.max(), err_ref.max())
+    finally:
+        k.close()
+
+
 @pytest.mark.parametrize("l,beta", [(1, 20), (3, 12)])
 def test_pbs_two_bit_rotation(gpu_ctx, oracle, l, beta):
     """tier.unroll == 2 (two key bits per blind-rotate iteration, csrc/pbs_core.h): every message decodes to f(m), the

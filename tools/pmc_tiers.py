@@ -10,7 +10,7 @@ from dctfhe import params as P
 from dctfhe.engine import Context, Keys
 
 # ciphertexts per launch as the ResNet-20 24x16^2 circuit issues them (one activation tensor, or the scheduler's 16384 chunk)
-COUNTS = {"T6a": 12288, "T4r": 12288, "T4r2": 12288, "Ba": 16384, "B": 12288, "T5a": 12288, "T4": 12288}
+COUNTS = {"T6a": 12288, "T4r": 12288, "T4r2": 12288, "Ba": 16384, "Ba2": 16384, "B": 12288, "T5a": 12288, "T4": 12288}
 
 
 def main():
