@@ -46,6 +46,9 @@ namespace dctfhe {
 #ifndef PBS_MB_BAR_B
 #define PBS_MB_BAR_B() ((void)0)     // no barrier after the fold: hipcc may hoist the next batch's loads over it (+3 %)
 #endif
+#ifndef PBS_MBG_BAR_B
+#define PBS_MBG_BAR_B() DCTFHE_SCHED_BARRIER()
+#endif
 #ifndef PBS_STD_BAR_B
 #define PBS_STD_BAR_B() DCTFHE_SCHED_BARRIER()
 #endif
@@ -358,7 +361,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
               const cplx bundle = cfma(m12, kk[2][q], cfma(m2, kk[1][q], cmul(m1, kk[0][q])));
               if constexpr (row == 0) out[q][j] = cmul(v[j], bundle); else out[q][j] = cfma(v[j], bundle, out[q][j]);
             });
-            DCTFHE_SCHED_BARRIER();
+            PBS_MBG_BAR_B();
           });
         });
       });
