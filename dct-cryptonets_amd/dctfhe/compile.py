@@ -525,15 +525,15 @@ def _estimate_noise(circ):
                     # entry far more often: the method's own inexactness, reported apart as boundary flips.)
                     return P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
                 if o.r > 0:
-                    bt = ps.tiers[o.ip[5]]
-                    v_bit_in = P.var_keyswitch(max(d_in, bt.k << bt.logN), bt) + P.var_modswitch(bt)
                     for i in range(o.r):
-                        pf_ += P.p_fail(0.25, 4.0 ** (o.p - i) * v_ + v_bit_in)
-                        step = bt
+                        step = ps.tiers[o.ip[5]]
                         if i >= coarse_from and o.ip[7] >= 0:
                             step = ps.tiers[o.ip[7]]
                         if coarse2_from is not None and i >= coarse2_from:
                             step = ps.tiers[c2]
+                        # the tier that runs the step key-switches to its own small key (own length, own noise) and mod-switches on its ring
+                        v_bit_in = P.var_keyswitch(max(d_in, step.k << step.logN), step) + P.var_modswitch(step)
+                        pf_ += P.p_fail(0.25, 4.0 ** (o.p - i) * v_ + v_bit_in)
                         v_ += P.var_pbs_out(step, ps.fft_noise_c)
                 return pf_ + P.p_fail(2.0 ** -(o.w + 2), v_ + v_tab_in)
 
