@@ -131,34 +131,40 @@ def default_params():
     the f64 FFT error (~ N^2 B^2) forces small digits, hence three levels (T6, T4r, T4r2).
     B is the one-bit tier of the rounding chain: margin 1/4, so a small ring, but two levels because its
     output is subtracted from a p-bit accumulator."""
-    t6 = TierSpec("T6", n=832, k=1, logN=13, l=3, beta=11, lk=6, betak=3)
+    # Key-switch gadget of the table tiers: base 4, nine levels (betak = 2, lk = 9) instead of base 8, six levels: the key-switch noise
+    # lk (B^2 + 2) / 12 sigma^2 drops from 33 to 13.5 units (0.64 bit of sigma), which buys 24 small-key bits per tier -- 808 / 768 / 728
+    # instead of 832 / 792 / 752, 3 % of every table bootstrap -- for 1.5x the work of their key switches (0.16 us of 5-25 us per
+    # ciphertext).  The one-bit tiers (half-box 1/4) take base 4 at the SAME depth, five levels: only the top 10 bits of a mask word are
+    # switched, the truncation (sigma 2^-6.8) stays below the key noise (2^-5.4), the gadget factor drops from 27.5 to 7.5 -- which buys
+    # 24 key bits (560 instead of 584) and lets the two-bit-rotation tier Ba2 take every step Ba used to run (ResNet-20, ResNet-18 3x32^2).
+    t6 = TierSpec("T6", n=808, k=1, logN=13, l=3, beta=11, lk=9, betak=2)
     # T4 / T4r look up 4-bit values (half-box 2^-6, four times the 6-bit tiers'): they afford a shorter small key -- and the
     # blind rotation is linear in n -- at the price of key-switch keys of their own (prefixes of the same small key, noise of
     # their own dimension).  752 / 792 are the smallest (steps of 8) that keep every site of the benchmark circuits at the
     # worst-site level of the 832-bit tiers (tools: the search behind profiles/r02_param_search.log).
-    t4 = TierSpec("T4", n=752, k=1, logN=11, l=1, beta=23, lk=6, betak=3, unroll=2)
-    b = TierSpec("B", n=584, k=2, logN=10, l=2, beta=14, lk=5, betak=3)
+    t4 = TierSpec("T4", n=728, k=1, logN=11, l=1, beta=23, lk=9, betak=2, unroll=2)
+    b = TierSpec("B", n=560, k=2, logN=10, l=2, beta=14, lk=5, betak=2)
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
-    t6a = TierSpec("T6a", n=832, k=1, logN=13, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
+    t6a = TierSpec("T6a", n=808, k=1, logN=13, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
     # Ba: one-level bit tier.  The output of rounding step i is amplified by 2^(p-j) only in the later steps j > i,
     # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
     # site, the first step from which Ba is safe.
-    ba = TierSpec("Ba", n=584, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3)
+    ba = TierSpec("Ba", n=560, k=2, logN=10, l=1, beta=23, lk=5, betak=2, ksk_share=3)
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
-    t4r = TierSpec("T4r", n=792, k=1, logN=11, l=3, beta=12, lk=6, betak=3)
+    t4r = TierSpec("T4r", n=768, k=1, logN=11, l=3, beta=12, lk=9, betak=2)
     # T4r2: the same refresh with two key bits per iteration (general form of the two-bit rotation, csrc/pbs_core.h): 10 %
     # fewer milliseconds per launch, output 0.7 bit noisier (three external products per pair).  The compiler takes it when every
     # site of the circuit stays inside the budget with it (the ResNet-20 circuits do) and falls back to T4r otherwise (two
     # sites of ResNet-18 3x32^2 would sit at 3.8e-12): ParamSet.table_tier_fallback_for_w.  Shares T4r's key-switch key.
-    t4r2 = TierSpec("T4r2", n=792, k=1, logN=11, l=3, beta=12, lk=6, betak=3, ksk_share=1, unroll=2)
+    t4r2 = TierSpec("T4r2", n=768, k=1, logN=11, l=3, beta=12, lk=9, betak=2, ksk_share=1, unroll=2)
     # T5a: one-level twin of the three-level 5-bit tier; the 5-bit residual-sum table is split the same way (T5a + T4r)
-    t5a = TierSpec("T5a", n=832, k=1, logN=12, l=1, beta=22, lk=6, betak=3, ksk_share=0, unroll=2)
+    t5a = TierSpec("T5a", n=808, k=1, logN=12, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
     # (a table of 5 or 6 input bits that feeds a convolution without the split would run on T6; with refresh_min_w = 5 none does)
     # Ba2: the one-level bit tier on the general two-bit rotation: 49.7 ms per launch of 16 384 against 63.6 (profiles/r02_exp_ablations.log),
     # output 0.5 bit noisier (2^-14.5): the compiler gives it the steps of a chain that can take that (78 % of them), Ba the ones before.
-    ba2 = TierSpec("Ba2", n=584, k=2, logN=10, l=1, beta=23, lk=5, betak=3, ksk_share=3, unroll=2)
+    ba2 = TierSpec("Ba2", n=560, k=2, logN=10, l=1, beta=23, lk=5, betak=2, ksk_share=3, unroll=2)
     return ParamSet(D=8192, tiers=[t6, t4r, t4, b, t6a, ba, t4r2, t5a, ba2], bit_tier=3, table_tier_for_w={4: 6, 6: 0},
                     table_tier_fallback_for_w={4: 1}, coarse_tier_for_w={4: 2, 5: 7, 6: 4}, bit_tier_coarse=5, bit_tier_coarse2=8, refresh_min_w=5,
                     input_dim=2048)

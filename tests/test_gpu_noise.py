@@ -43,3 +43,28 @@ def test_output_noise_matches_model(gpu_ctx):
         print("sigma_out log2 (measured, model):", {k: (round(a, 2), round(b, 2)) for k, (a, b) in report.items()})
     finally:
         keys.close()
+
+
+def test_keyswitch_noise_matches_model(gpu_ctx, oracle):
+    """the other half of every site's budget: what the key switch of each tier (its own gadget base, depth and small-key length) adds to
+    a fresh ciphertext, against params.var_keyswitch over the effective dimension (the client masks the first input_dim key bits only)"""
+    from dctfhe import params as P
+    from dctfhe.engine import Keys
+    ps = P.default_params()
+    keys = Keys(gpu_ctx, P.to_c_params(ps), seed=5)
+    try:
+        _, s = keys.export_secret()
+        rng = np.random.default_rng(1)
+        msgs = rng.integers(0, 16, 4096).astype(np.uint64) << np.uint64(59)
+        cts = keys.encrypt(msgs)
+        deff = ps.input_dim or ps.D
+        report = {}
+        for ti, t in enumerate(ps.tiers):
+            small = keys.keyswitch(ti, cts)
+            err = _cent(oracle.lwe_phase(s[:t.n].copy(), t.n, small) - msgs)
+            measured, model = err.std(), math.sqrt(P.var_keyswitch(deff, t) + ps.input_sigma ** 2)
+            report[t.name] = (round(math.log2(measured), 2), round(math.log2(model), 2))
+            assert 0.7 * model < measured < 1.3 * model, (t.name, report[t.name])
+        print("sigma after key switch log2 (measured, model):", report)
+    finally:
+        keys.close()
