@@ -120,10 +120,10 @@ def p_fail(margin, var):
 def default_params():
     """Exact-evaluation set: every table site fails with probability < 1e-12 under the model above.
 
-    Small-key lengths: n = 832 for the table tiers and n = 584 for the one-bit tiers are the smallest (in steps of 8) that
-    keep every site of the four benchmark circuits under that budget once the key switch sums only over the effective
-    dimension of its input (2048 for everything downstream of a refresh or of the client, who encrypts under the first
-    2048 key bits: input_dim); the blind rotation is linear in n.
+    Small-key lengths: n = 808 for the 5/6-bit table tiers, 768 / 728 for the 4-bit ones and 560 for the one-bit tiers are the
+    smallest (in steps of 8) that keep every site of the benchmark circuits under that budget with base-4 key-switch gadgets
+    (below) and a key switch that sums only over the effective dimension of its input (2048 for everything downstream of a
+    refresh or of the client, who encrypts under the first 2048 key bits: input_dim); the blind rotation is linear in n.
 
     T6 (6-bit tables after a rounded accumulator) needs N = 8192: its mod-switch noise must stay 6.4
     sigma inside a 2^-8 half-box.  T5a/T4 serve the 5-bit residual-sum tables and the 4-bit rescale
