@@ -839,9 +839,12 @@ static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t cou
   if (L_out == 0) L_out = (size_t)K->p.D + 1;
   if (L_out < (size_t)ring + 1) return fail("bootstrap output rows of %zu words cannot hold a ring of %d", L_out, ring);
   a.out = d_out; a.D_out = (int)L_out - 1; a.accumulate = accumulate; a.body_add = body_add; a.dummy = K->d_dummy; a.bsk_wrap = 0;
-  // L2 warm-up: 1/16 of the next key blocks per workgroup; the paired two-bit kernel at N = 2048 measures 3 % better without
-  // (profiles/r02_exp_ablations.log: 22.5 vs 23.2 ms), every other barrier-coupled kernel better with (T4r 82.4 vs 86.3, T5a 25.7 vs 26.6)
-  a.pf_parts = (t.unroll == 2 && t.logN == 11 && t.l == 1) ? 0 : 16;
+  // L2 warm-up: each workgroup touches 1/pf_parts of the next key blocks; the paired two-bit kernel at N = 2048 measures 3 % better
+  // without (profiles/r02_exp_ablations.log: 22.5 vs 23.2 ms), every other barrier-coupled kernel better with (T4r 82.4 vs 86.3, T5a 25.7
+  // vs 26.6).  The parts are dealt by blockIdx / 8, i.e. per XCD: with one 512-thread workgroup per CU an XCD holds 32 of them, and 32
+  // parts -- every line touched once per XCD instead of twice -- is worth 4 % on the N = 8192 kernel (288 vs 300 ms per 12 288; 24, 40,
+  // 48, 64 parts: 302, 318, 325, 330), nothing at N = 4096 (143.4 vs 144.0) and N = 2048 three levels (180.9 vs 181.1).
+  a.pf_parts = (t.unroll == 2 && t.logN == 11 && t.l == 1) ? 0 : t.logN >= 13 ? 32 : 16;
   const int h = tm ? tm->begin(tier) : -1;
   CHK(launch_pbs(t, a, K->ctx->stream));
   if (tm) tm->end(h);

@@ -286,7 +286,7 @@ static int pf_guard_case(int n_in, int wrap, int pf_parts) {
 
 int main() {
   int fail = 0;
-  // every geometry the library launches (dctfhe.hip PBS_CASES used by dctfhe/params.py catalogues), pf_parts as launched (16),
+  // every geometry the library launches (dctfhe.hip PBS_CASES used by dctfhe/params.py catalogues), pf_parts as launched (16; 32 at N = 8192),
   // the other legal settings, and the cache-experiment switch
   fail |= pf_guard_case<13, 1, 1, 8, 1>(4, 0, 16);
   fail |= pf_guard_case<13, 1, 1, 8, 1>(4, 0, 8);
@@ -297,6 +297,7 @@ int main() {
   fail |= pf_guard_case<11, 1, 3, 8>(3, 0, 16);
   fail |= pf_guard_case<12, 1, 3, 8>(2, 0, 16);
   fail |= pf_guard_case<13, 1, 3, 8>(2, 0, 16);
+  fail |= pf_guard_case<13, 1, 3, 8>(2, 0, 32);
   fail |= pf_guard_case<10, 2, 1, 8>(3, 0, 16);
   fail |= pf_guard_case<10, 2, 2, 8>(3, 0, 16);
   fail |= pf_guard_case<12, 1, 2, 8>(2, 0, 16);
