@@ -110,3 +110,53 @@ def test_exact_catalogue_keeps_every_site_in_budget(name, in_ch, img, front):
     c = cc.compile_model(model, x, rounding_threshold_bits=6, n_bits=5)
     assert c.worst_site_failure <= 1e-12, c.worst_site_failure
     assert "T6" not in c.pbs_counts() and "T5" not in c.pbs_counts()        # every wide conv-feeding table is split
+
+
+def _variant(changes):
+    """default catalogue with some tiers replaced (noise levels re-derived from the new key lengths)"""
+    import dataclasses
+    from dctfhe import params as P
+    ps = P.default_params()
+    tiers = list(ps.tiers)
+    for name, ch in changes.items():
+        i = [t.name for t in tiers].index(name)
+        tiers[i] = dataclasses.replace(tiers[i], lwe_sigma=0.0, **ch)
+    return dataclasses.replace(ps, tiers=tiers)
+
+
+def test_rounding_chain_hands_over_b_ba_ba2_in_order():
+    """with the noisier base-8 key switch of the one-bit tiers (the catalogue before the base-4 gadgets) a rounding chain needs all three
+    bit tiers: B first, then Ba, then Ba2 -- never back -- and the blob carries both hand-over points (ip[8], ip[11])"""
+    from dctfhe import compile as cc, models
+    from dctfhe.synthetic import synthetic_dct_batch
+    old_bits = dict(n=584, lk=5, betak=3)
+    ps = _variant({"B": old_bits, "Ba": old_bits, "Ba2": old_bits})
+    c = cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7), param_set=ps)
+    counts = c.pbs_counts()
+    assert counts["B"] > 0 and counts["Ba"] > 0 and counts["Ba2"] > counts["Ba"]
+    names = [t.name for t in ps.tiers]
+    seen_three = False
+    for o in c.ops:
+        if o.type != cc.OP_LUT or o.r == 0:
+            continue
+        chain = [names[cc.step_tier(o, i)] for i in range(o.r)]
+        order = [{"B": 0, "Ba": 1, "Ba2": 2}[x] for x in chain]
+        assert order == sorted(order), chain
+        seen_three |= len(set(chain)) == 3
+        if o.ip[11] >= 0:
+            assert names[o.ip[11] >> 8] == "Ba2" and o.ip[8] <= (o.ip[11] & 255) < o.r
+    assert seen_three
+    assert c.worst_site_failure < 1e-12
+    # the shipped catalogue: Ba2 takes every step Ba would
+    d = cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7)).pbs_counts()
+    assert d.get("Ba", 0) == 0 and d["Ba2"] > 0 and d["B"] > 0
+
+
+def test_table_tier_falls_back_when_a_site_leaves_the_budget():
+    """a refresh tier that is too noisy for some site (here: T4r2 with 15-bit digits) sends the whole circuit to its quieter fallback T4r"""
+    from dctfhe import compile as cc, models
+    from dctfhe.synthetic import synthetic_dct_batch
+    c = cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7), param_set=_variant({"T4r2": dict(beta=15)}))
+    counts = c.pbs_counts()
+    assert counts.get("T4r2", 0) == 0 and counts["T4r"] > 0 and c.worst_site_failure < 1e-12
+    assert cc.compile_model(models.ResNet20QAT(4, 24, 16), synthetic_dct_batch(24, seed=7)).pbs_counts().get("T4r", 0) == 0

@@ -89,3 +89,43 @@ def test_encrypted_config5_prefix_bit_exact():
         assert np.array_equal(got, want), (got, want)
     finally:
         qm.close()
+
+
+def _catalogue_variant(changes):
+    import dataclasses
+    from dctfhe import params as P
+    ps = P.default_params()
+    tiers = list(ps.tiers)
+    for name, ch in changes.items():
+        i = [t.name for t in tiers].index(name)
+        tiers[i] = dataclasses.replace(tiers[i], lwe_sigma=0.0, **ch)
+    return dataclasses.replace(ps, tiers=tiers)
+
+
+@pytest.mark.parametrize("changes,expect_used,expect_unused", [
+    # the one-bit tiers on their former base-8 key switch: a rounding chain then needs B, Ba AND Ba2 (the shipped catalogue has no Ba steps)
+    ({"B": dict(n=584, lk=5, betak=3), "Ba": dict(n=584, lk=5, betak=3), "Ba2": dict(n=584, lk=5, betak=3)}, ("B", "Ba", "Ba2", "T4r2"), ()),
+    # a two-bit refresh too noisy for the budget: the compiler falls back to the one-bit-chain refresh T4r
+    ({"T4r2": dict(beta=15)}, ("T4r",), ("T4r2",)),
+], ids=["chain B-Ba-Ba2", "fallback T4r"])
+def test_encrypted_prefix_on_catalogue_variants_bit_exact(changes, expect_used, expect_unused):
+    """paths of the engine the shipped catalogue no longer walks on the benchmark circuits (three-way rounding chains, the fallback refresh
+    tier), on the full-size rings: the config-#5 prefix of the test above, encrypted == integer circuit"""
+    from dctfhe import frontend, models, synthetic
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=112, channels=48)
+    planes = np.stack([tf(im) for im in synthetic.synthetic_images(18, 7, size=96)]).astype(np.float32)
+    crops = planes[:, :, 40:56, 40:56]
+    model = models.ResNet18QAT(bit_width=4, in_channels=48, img_size=112)
+    prefix = models.trunk_prefix(model, n_blocks=2, avgpool_kernel=5)
+    qm = compile_brevitas_qat_model(prefix, crops[:16], n_bits=5, rounding_threshold_bits=6, p_error=0.01, param_set=_catalogue_variant(changes))
+    try:
+        counts = qm.compiled.pbs_counts()
+        assert all(counts.get(t, 0) > 0 for t in expect_used) and all(counts.get(t, 0) == 0 for t in expect_unused), counts
+        q = qm.quantize_input(crops[16:17])
+        want = _oracle(qm, q)
+        qm.fhe_circuit.keygen(seed=2)
+        got = qm.forward_quantized(q, "execute")
+        assert np.array_equal(got, want), (got, want)
+    finally:
+        qm.close()
