@@ -2,6 +2,7 @@
 // compiled circuit and issues batched HIP launches, and the C ABI of include/dctfhe.h.
 // gfx950 only.  No CPU fallback anywhere: every entry point needs a live HIP device.
 #include <hip/hip_runtime.h>
+#include <sys/random.h>
 
 #include <algorithm>
 #include <array>
@@ -81,6 +82,12 @@ struct dctfhe_client_key {
   dctfhe_params p{};
   uint8_t seed[32] = {};
   rng_key sec{}, pub{};          // ChaCha20 keys: secret (key bits, noise) and public (masks)
+  // ENCRYPTION randomness is per HANDLE, not per seed: its two generator keys are derived from the seed AND a 128-bit nonce drawn from
+  // the OS when the handle is created.  (Key material stays a pure function of the seed.  Before, a client that re-created its key from
+  // the persisted seed -- or a second process holding the seed -- re-drew the very masks and noise of earlier ciphertexts: ct1 - ct2 =
+  // (0, m1 - m2).  ADVICE r2.)
+  uint8_t nonce[16] = {};
+  rng_key enc_sec{}, enc_pub{};
   uint8_t *d_S = nullptr, *d_s = nullptr;
   uint8_t* d_spair[DCTFHE_MAX_TIERS] = {};   // unroll 2: derived secret (s1(1-s2), (1-s1)s2, s1 s2) per pair
   uint64_t enc_calls = 0;        // every dctfhe_encrypt call draws from fresh streams
@@ -252,6 +259,19 @@ static int tier_ppt(const dctfhe_tier& t) {
   return 0;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function on the CURRENT device: once per (call site, device), not once
+// per process (a process with contexts on two GPUs would have failed on the second at every launch above 64 KB of LDS)
+#define SET_LDS_ATTR(kernel, bytes)                                                                  \
+  do {                                                                                               \
+    static uint64_t done_mask = 0;                                                                   \
+    int dev_ = 0;                                                                                    \
+    HIPCHK(hipGetDevice(&dev_));                                                                     \
+    if (dev_ < 0 || dev_ >= 64 || !((done_mask >> dev_) & 1)) {                                      \
+      HIPCHK(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      if (dev_ >= 0 && dev_ < 64) done_mask |= 1ull << dev_;                                         \
+    }                                                                                                \
+  } while (0)
+
 static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st) {
   if (a.count == 0) return 0;
   // the kernel's L2 warm-up contract (pbs_core.h): callers pad the key by PBS_PF_DIST iterations (eval_alloc does)
@@ -264,11 +284,7 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
     using G = pbs_geom<LN, K_, L_, P_>;                                                              \
     constexpr int GR = groups_for<LN, K_, L_, P_>();                                                 \
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                 \
-    static bool attr_done = false;                                                                   \
-    if (!attr_done) {                                                                                \
-      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, K_, L_, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      attr_done = true;                                                                              \
-    }                                                                                                \
+    SET_LDS_ATTR((pbs_kernel<LN, K_, L_, P_, GR>), lds);                                             \
     const unsigned grid = (unsigned)((a.count + GR - 1) / GR);                                       \
     hipLaunchKernelGGL((pbs_kernel<LN, K_, L_, P_, GR>), dim3(grid), dim3(G::T * GR), lds, st, a);   \
     HIPCHK(hipGetLastError());                                                                       \
@@ -282,11 +298,7 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
     /* N = 4096: two ciphertexts per 512-thread workgroup share their key lines (28.5 vs 30.8 ms) */  \
     constexpr int GR = LN == 12 ? 2 : groups_for<LN, 1, 1, 8>();                                     \
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;                                    \
-    static bool attr_done = false;                                                                   \
-    if (!attr_done) {                                                                                \
-      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<LN, 1, 1, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      attr_done = true;                                                                              \
-    }                                                                                                \
+    SET_LDS_ATTR((pbs_kernel<LN, 1, 1, 8, GR, 1>), lds);                                             \
     const unsigned grid = (unsigned)((a.count + GR - 1) / GR);                                       \
     hipLaunchKernelGGL((pbs_kernel<LN, 1, 1, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);   \
     HIPCHK(hipGetLastError());                                                                       \
@@ -302,11 +314,7 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
     using G = pbs_geom<11, 1, 3, 8, 1>;
     constexpr int GR = 4;
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<11, 1, 3, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_done = true;
-    }
+    SET_LDS_ATTR((pbs_kernel<11, 1, 3, 8, GR, 1>), lds);
     const unsigned grid = (unsigned)((a.count + GR - 1) / GR);
     hipLaunchKernelGGL((pbs_kernel<11, 1, 3, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -315,13 +323,22 @@ static int launch_pbs(const dctfhe_tier& t, const pbs_launch& a, hipStream_t st)
   if (t.logN == 10 && t.k == 2 && t.l == 1 && t.unroll == 2) {
     // general two-bit rotation for the one-level bit tier (Ba2): one wave per ciphertext, four per workgroup
     using G = pbs_geom<10, 2, 1, 8, 1>;
+    if (t.key_lds) {
+      // the eight ciphertexts of a 512-thread workgroup share every key tile through an LDS ring filled by LDS-DMA (pbs_core.h, KLDS):
+      // one copy of the key per CU through L1 instead of eight.  Same results; measured no faster than the free-running form below
+      // (47.6 against 47.5 ms per 16 384: profiles/r03_exp_t4r2_ulow_ba2_keylds.log) -- the kernel sits at its instruction-issue
+      // rate at the clock the chip holds, not at the L1 path -- so the catalogue leaves it off.
+      constexpr int GR8 = 8, KL = 4;
+      const size_t lds8 = pbs_lds_bytes<10, 2, 1, 8, 1, KL>(GR8);
+      SET_LDS_ATTR((pbs_kernel<10, 2, 1, 8, GR8, 1, KL>), lds8);
+      const unsigned grid8 = (unsigned)((a.count + GR8 - 1) / GR8);
+      hipLaunchKernelGGL((pbs_kernel<10, 2, 1, 8, GR8, 1, KL>), dim3(grid8), dim3(G::T * GR8), lds8, st, a);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     constexpr int GR = 4;
     const size_t lds = G::TW_BYTES + (size_t)GR * G::GROUP_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-      HIPCHK(hipFuncSetAttribute((const void*)pbs_kernel<10, 2, 1, 8, GR, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_done = true;
-    }
+    SET_LDS_ATTR((pbs_kernel<10, 2, 1, 8, GR, 1>), lds);
     const unsigned grid = (unsigned)((a.count + GR - 1) / GR);
     hipLaunchKernelGGL((pbs_kernel<10, 2, 1, 8, GR, 1>), dim3(grid), dim3(G::T * GR), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -348,11 +365,7 @@ static int launch_bsk_fourier(const dctfhe_tier& t, const uint64_t* polys, size_
     using F = fft_geom<LN - 1, P_>;                                                                  \
     constexpr int GR = groups_for<LN, K_, L_, P_>();                                                 \
     const size_t lds = (size_t)F::TW_ELEMS * 16 + (size_t)GR * F::EXCH_ELEMS * 16;                   \
-    static bool attr_done = false;                                                                   \
-    if (!attr_done) {                                                                                \
-      HIPCHK(hipFuncSetAttribute((const void*)k_bsk_fourier<LN, P_, GR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      attr_done = true;                                                                              \
-    }                                                                                                \
+    SET_LDS_ATTR((k_bsk_fourier<LN, P_, GR>), lds);                                                  \
     const unsigned grid = (unsigned)((npoly + GR - 1) / GR);                                         \
     hipLaunchKernelGGL((k_bsk_fourier<LN, P_, GR>), dim3(grid), dim3(F::T * GR), lds, st, polys, npoly, tw, out); \
     HIPCHK(hipGetLastError());                                                                       \
@@ -397,12 +410,17 @@ extern "C" int dctfhe_ctx_synchronize(dctfhe_ctx* c) {
 
 // ------------------------------------------------------------------------------------------ keygen
 static int check_params(const dctfhe_params* p) {
+  // this is the only gate in front of an untrusted evaluation-key blob (dctfhe_eval_keys_import): every field gets both bounds, and
+  // the caps keep every size computed from them (eval_blob_size, key allocations) far inside size_t
   if (p->n_tiers < 1 || p->n_tiers > DCTFHE_MAX_TIERS) return fail("n_tiers out of range");
-  if (p->D < 4 || p->D % 4) return fail("D must be a positive multiple of 4");
+  if (p->D < 4 || p->D % 4 || p->D > (1 << 16)) return fail("D must be a positive multiple of 4, at most 65536");
+  if (p->n_max < 1 || p->n_max > (1 << 13)) return fail("n_max out of range (1 .. 8192)");
   if (p->input_dim < 0 || p->input_dim > p->D) return fail("input_dim out of range");
+  if (!(p->input_sigma >= 0.0) || p->input_sigma > 1.0) return fail("input_sigma out of range");
   for (int i = 0; i < p->n_tiers; i++) {
     const dctfhe_tier& t = p->tiers[i];
     if (t.n < 1 || t.n > p->n_max) return fail("tier %d: n out of range", i);
+    if (t.k < 1 || t.k > 2 || t.logN < 8 || t.logN > 13) return fail("tier %d: k or logN out of range", i);
     if ((t.k << t.logN) > p->D) return fail("tier %d: k*N exceeds D", i);
     if (t.l * t.beta > 63 || t.l < 1 || t.l > 3 || t.beta < 1 || (t.l >= 2 && t.beta > 16) || (t.l == 1 && t.beta > 28))
       return fail("tier %d: bad bootstrap gadget (l <= 3; beta <= 16 when l >= 2, <= 28 when l == 1: 32-bit accumulators)", i);
@@ -413,7 +431,11 @@ static int check_params(const dctfhe_params* p) {
       if (!(paired || general) || (t.n & 1))
         return fail("tier %d: unroll 2 needs n even and (k, l, N) = (1, 1, >= 2048), (1, 3, 2048) or (2, 1, 1024)", i);
     }
-    if (t.lk * t.betak > 63 || t.lk < 1 || t.betak > 8) return fail("tier %d: bad key-switch gadget (betak <= 8)", i);
+    if (t.k < 1 || t.k > 2 || t.logN < 8 || t.logN > 13) return fail("tier %d: k or logN out of range", i);
+    if (t.lk < 1 || t.lk > 63 || t.betak < 1 || t.betak > 8 || t.lk * t.betak > 63) return fail("tier %d: bad key-switch gadget (1 <= betak <= 8, lk >= 1, lk * betak <= 63)", i);
+    if (!(t.lwe_sigma >= 0.0) || t.lwe_sigma > 1.0 || !(t.glwe_sigma >= 0.0) || t.glwe_sigma > 1.0) return fail("tier %d: noise parameter out of range", i);
+    if (t.key_lds != 0 && !(t.key_lds == 1 && t.unroll == 2 && t.k == 2 && t.l == 1 && t.logN == 10))
+      return fail("tier %d: key_lds is 0, or 1 on the (k, l, N, unroll) = (2, 1, 1024, 2) tier", i);
     if (!tier_ppt(t)) return fail("tier %d: no kernel for logN=%d k=%d l=%d", i, t.logN, t.k, t.l);
     if (t.ksk_share >= i) return fail("tier %d: ksk_share must name an earlier tier", i);
     if (t.ksk_share >= 0) {
@@ -437,6 +459,22 @@ static rng_key key_from_bytes(const uint8_t* b) {
   return k;
 }
 
+// (seed, nonce) -> the generator keys of dctfhe_encrypt: a key-derivation key that only the seed determines (one ChaCha20 block of the
+// secret generator key at a stream of its own), one block of THAT at (stream, counter) = the nonce for the noise key, and the mask key one
+// block of the noise key -- the same secret -> public step as for the key material.
+static void derive_encrypt_keys(dctfhe_client_key* C) {
+  uint32_t o[16];
+  rng_key kdf;
+  chacha20_block(C->sec, STREAM_ENCKDF, 0, o);
+  for (int i = 0; i < 8; i++) kdf.k[i] = o[i];
+  uint64_t n0 = 0, n1 = 0;
+  for (int i = 0; i < 8; i++) { n0 |= (uint64_t)C->nonce[i] << (8 * i); n1 |= (uint64_t)C->nonce[8 + i] << (8 * i); }
+  chacha20_block(kdf, n0, n1, o);
+  for (int i = 0; i < 8; i++) C->enc_sec.k[i] = o[i];
+  chacha20_block(C->enc_sec, STREAM_PUBKEY, 0, o);
+  for (int i = 0; i < 8; i++) C->enc_pub.k[i] = o[i];
+}
+
 extern "C" int dctfhe_client_key_create(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t* seed32, dctfhe_client_key** out) {
   if (!ctx || !params || !seed32 || !out) return fail("dctfhe_client_key_create: null argument");
   CHK(check_params(params));
@@ -449,6 +487,15 @@ extern "C" int dctfhe_client_key_create(dctfhe_ctx* ctx, const dctfhe_params* pa
     uint32_t o[16];
     chacha20_block(C->sec, STREAM_PUBKEY, 0, o);
     for (int i = 0; i < 8; i++) C->pub.k[i] = o[i];
+  }
+  {  // per-handle encryption nonce from the OS
+    size_t got = 0;
+    while (got < sizeof C->nonce) {
+      const ssize_t r = getrandom(C->nonce + got, sizeof C->nonce - got, 0);
+      if (r <= 0) return fail("dctfhe_client_key_create: the OS gave no random bytes for the encryption nonce (getrandom)");
+      got += (size_t)r;
+    }
+    derive_encrypt_keys(C.get());
   }
   hipStream_t st = ctx->stream;
   const int D = params->D;
@@ -474,11 +521,7 @@ extern "C" int dctfhe_client_key_destroy(dctfhe_client_key* C) { delete C; retur
 static int gen_bsk_std_chunk(dctfhe_client_key* C, int tier, int i0, int ni, uint64_t* d_out) {
   const dctfhe_tier& t = C->p.tiers[tier];
   const int N = 1 << t.logN, rows = (t.k + 1) * t.l;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_bsk_gen_std, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    attr_done = true;
-  }
+  SET_LDS_ATTR(k_bsk_gen_std, 8192 * 8);
   // unroll 2: the "secret" is the pair secret of 3n/2 bits, i0/ni count its blocks
   const uint8_t* bits = t.unroll == 2 ? C->d_spair[tier] : C->d_s;
   hipLaunchKernelGGL(k_bsk_gen_std, dim3((unsigned)(ni * rows)), dim3(256), (size_t)N * 8, C->ctx->stream, bits, C->d_S, i0, t.k, N,
@@ -720,44 +763,64 @@ extern "C" int dctfhe_rng_device(dctfhe_ctx* ctx, const uint8_t* key32, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------ client ops
-extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* phases, size_t count, uint64_t* cts) {
+// rows of `dim` mask words + body, input_dim <= dim <= D
+extern "C" int dctfhe_encrypt_rows(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* phases, size_t count, int dim, uint64_t* cts) {
+  if (!ctx || !C || (count && (!phases || !cts))) return fail("dctfhe_encrypt: null argument");
+  const int D = C->p.D, dim_eff = C->p.input_dim > 0 ? C->p.input_dim : D;
+  if (dim < dim_eff || dim > D) return fail("dctfhe_encrypt: rows of %d mask words; these parameters mask %d and the key has %d", dim, dim_eff, D);
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
-  const int D = C->p.D;
+  const size_t L = (size_t)dim + 1;
   DevBuf d_ph, d_ct;
   HIPCHK(d_ph.alloc(count * 8));
-  HIPCHK(d_ct.alloc(count * (size_t)(D + 1) * 8));
+  HIPCHK(d_ct.alloc(count * L * 8));
   HIPCHK(hipMemcpyAsync(d_ph.p, phases, count * 8, hipMemcpyHostToDevice, ctx->stream));
-  // fresh streams per call: a (mask, noise) pair is never drawn twice under one key
+  // fresh streams per call: a (mask, noise) pair is never drawn twice under one handle; handles differ by their nonce
   const uint64_t stream = (uint64_t)STREAM_ENC + ((++C->enc_calls) << 16);
-  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, D, C->p.input_dim > 0 ? C->p.input_dim : D, d_ph.as<uint64_t>(),
-                     C->p.input_sigma, C->pub, C->sec, stream, d_ct.as<uint64_t>());
+  hipLaunchKernelGGL(k_lwe_encrypt, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, D, dim, dim_eff, d_ph.as<uint64_t>(),
+                     C->p.input_sigma, C->enc_pub, C->enc_sec, stream, d_ct.as<uint64_t>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(cts, d_ct.p, count * (size_t)(D + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(cts, d_ct.p, count * L * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
-// two processes that hold the same client key (ranks of one job) must not draw the same encryption streams: each sets
-// its own counter range, e.g. rank << 32
+extern "C" int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* phases, size_t count, uint64_t* cts) {
+  if (!C) return fail("dctfhe_encrypt: null argument");
+  return dctfhe_encrypt_rows(ctx, C, phases, count, C->p.D, cts);
+}
+// a handle's position in its own encryption streams (the streams themselves differ from handle to handle by the nonce)
 extern "C" int dctfhe_client_key_set_encrypt_counter(dctfhe_client_key* C, uint64_t next_call) {
   if (!C) return fail("null client key");
   if (next_call >= (1ULL << 47)) return fail("encrypt counter out of range");
   C->enc_calls = next_call;
   return 0;
 }
-extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* cts, size_t count, uint64_t* phases) {
+// reproducible experiments and tests only: fix the nonce (and with it every mask and noise value dctfhe_encrypt will draw)
+extern "C" int dctfhe_client_key_set_encrypt_nonce(dctfhe_client_key* C, const uint8_t* nonce16) {
+  if (!C || !nonce16) return fail("dctfhe_client_key_set_encrypt_nonce: null argument");
+  memcpy(C->nonce, nonce16, sizeof C->nonce);
+  derive_encrypt_keys(C);
+  return 0;
+}
+extern "C" int dctfhe_decrypt_rows(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* cts, size_t count, int dim, uint64_t* phases) {
+  if (!ctx || !C || (count && (!phases || !cts))) return fail("dctfhe_decrypt: null argument");
+  if (dim < 0 || dim > C->p.D) return fail("dctfhe_decrypt: rows of %d mask words, the key has %d", dim, C->p.D);
   if (count == 0) return 0;
   HIPCHK(hipSetDevice(ctx->device));
-  const int D = C->p.D;
+  const size_t L = (size_t)dim + 1;
   DevBuf d_ph, d_ct;
   HIPCHK(d_ph.alloc(count * 8));
-  HIPCHK(d_ct.alloc(count * (size_t)(D + 1) * 8));
-  HIPCHK(hipMemcpyAsync(d_ct.p, cts, count * (size_t)(D + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_lwe_phase, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, D, d_ct.as<uint64_t>(), d_ph.as<uint64_t>());
+  HIPCHK(d_ct.alloc(count * L * 8));
+  HIPCHK(hipMemcpyAsync(d_ct.p, cts, count * L * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_lwe_phase, dim3((unsigned)count), dim3(256), 0, ctx->stream, C->d_S, dim, d_ct.as<uint64_t>(), d_ph.as<uint64_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(phases, d_ph.p, count * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+extern "C" int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_client_key* C, const uint64_t* cts, size_t count, uint64_t* phases) {
+  if (!C) return fail("dctfhe_decrypt: null argument");
+  return dctfhe_decrypt_rows(ctx, C, cts, count, C->p.D, phases);
 }
 
 // ------------------------------------------------------------------------------------------ device-level building blocks
@@ -918,6 +981,12 @@ static int round_chain_deff(const dctfhe_keys* K, int src_deff, const StepTiers&
   return d;
 }
 
+// can the key switch of `tier` run on the first deff rows of its key only?  (matrix-core path, whole 64-row steps; otherwise it walks the
+// whole stored row and every word of it has to be meaningful)
+static bool ks_narrows(const dctfhe_keys* K, int tier, int deff) {
+  return K->tiers[tier].d_kskT != nullptr && ((size_t)deff * (size_t)K->p.tiers[tier].lk) % 64 == 0;
+}
+
 static int alloc_lut_scratch(dctfhe_keys* K, size_t chunk, LutScratch* sc) {
   int lkmax = 1, nmax = 1;
   for (int i = 0; i < K->p.n_tiers; i++) { lkmax = std::max(lkmax, K->p.tiers[i].lk); nmax = std::max(nmax, K->p.tiers[i].n); }
@@ -1052,6 +1121,74 @@ extern "C" int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int bat
   CHK(dev_conv2d(ctx->stream, d_in.as<uint64_t>(), batch, Cin, H, W, L, L - 1, d_w.as<int8_t>(), &pk[0], Cout, KH, KW, stride, pad, d_out.as<uint64_t>(), L));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(out, d_out.p, nout * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- K2 (residual add, rounding offset / shift, window-sum pooling) one kernel at a time on host buffers.  Rows of `dim` mask words +
+// body of which the first `deff` may be non-zero -- the storage form of the session's tensors, so that the kernels are checked at mixed
+// effective dimensions outside a circuit (reference backbone.py:102 torch.add, :276 AvgPool2d).
+static int rows_ok(const char* what, int dim, int deff) {
+  if (dim < 0 || deff < 0 || deff > dim || dim > (1 << 16)) return fail("%s: rows of %d mask words with effective dimension %d", what, dim, deff);
+  return 0;
+}
+extern "C" int dctfhe_add_rows(dctfhe_ctx* ctx, const uint64_t* a, int dim_a, int deff_a, const uint64_t* b, int dim_b, int deff_b, size_t count, int dim_o,
+                               uint64_t* out) {
+  if (!ctx || !a || !b || !out) return fail("dctfhe_add_rows: null argument");
+  CHK(rows_ok("dctfhe_add_rows (a)", dim_a, deff_a));
+  CHK(rows_ok("dctfhe_add_rows (b)", dim_b, deff_b));
+  if (dim_o < std::max(deff_a, deff_b) || dim_o > (1 << 16)) return fail("dctfhe_add_rows: output rows of %d mask words cannot hold the sum (%d needed)", dim_o, std::max(deff_a, deff_b));
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t La = (size_t)dim_a + 1, Lb = (size_t)dim_b + 1, Lo = (size_t)dim_o + 1;
+  DevBuf da, db, d_o;
+  HIPCHK(da.alloc(count * La * 8)); HIPCHK(db.alloc(count * Lb * 8)); HIPCHK(d_o.alloc(count * Lo * 8));
+  HIPCHK(hipMemcpy(da.p, a, count * La * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db.p, b, count * Lb * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_add, dim3(ew_grid(count * Lo)), dim3(256), 0, ctx->stream, da.as<uint64_t>(), La, (size_t)deff_a, db.as<uint64_t>(), Lb, (size_t)deff_b,
+                     d_o.as<uint64_t>(), Lo, count);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d_o.p, count * Lo * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+// inout: rows of dim_o + 1 words; the kernel writes the first nwords mask words (a << shift; zero from deff_a on) and the body
+// ((body << shift) + body_add) and leaves the words in between as they were (what the rounding chain relies on: dctfhe_session_run)
+extern "C" int dctfhe_affine_rows(dctfhe_ctx* ctx, const uint64_t* a, int dim_a, int deff_a, size_t count, int nwords, int shift, uint64_t body_add, int dim_o,
+                                  uint64_t* inout) {
+  if (!ctx || !a || !inout) return fail("dctfhe_affine_rows: null argument");
+  CHK(rows_ok("dctfhe_affine_rows", dim_a, deff_a));
+  if (dim_o < 0 || dim_o > (1 << 16) || nwords < 0 || nwords > dim_o || shift < 0 || shift > 63) return fail("dctfhe_affine_rows: bad output geometry (nwords <= dim_o, 0 <= shift <= 63)");
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t La = (size_t)dim_a + 1, Lo = (size_t)dim_o + 1;
+  DevBuf da, d_o;
+  HIPCHK(da.alloc(count * La * 8)); HIPCHK(d_o.alloc(count * Lo * 8));
+  HIPCHK(hipMemcpy(da.p, a, count * La * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_o.p, inout, count * Lo * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_affine, dim3(ew_grid(count * ((size_t)nwords + 1))), dim3(256), 0, ctx->stream, da.as<uint64_t>(), La, (size_t)deff_a, d_o.as<uint64_t>(), Lo, count,
+                     (size_t)nwords, shift, body_add);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(inout, d_o.p, count * Lo * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+// in [batch][C][H][W] rows -> out [batch][C][H/K][W/K] rows: window sums with floor semantics (border rows / columns dropped)
+extern "C" int dctfhe_sum_pool_rows(dctfhe_ctx* ctx, const uint64_t* in, int dim_in, int deff_in, int batch, int C, int H, int W, int K, int dim_o, uint64_t* out) {
+  if (!ctx || !in || !out) return fail("dctfhe_sum_pool_rows: null argument");
+  CHK(rows_ok("dctfhe_sum_pool_rows", dim_in, deff_in));
+  if (batch < 1 || C < 1 || H < 1 || W < 1 || K < 1 || H / K < 1 || W / K < 1) return fail("dctfhe_sum_pool_rows: bad geometry");
+  if (dim_o < deff_in || dim_o > (1 << 16)) return fail("dctfhe_sum_pool_rows: output rows of %d mask words cannot hold the sums (%d needed)", dim_o, deff_in);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t Li = (size_t)dim_in + 1, Lo = (size_t)dim_o + 1;
+  const int Ho = H / K, Wo = W / K;
+  const size_t nin = (size_t)batch * C * H * W * Li, nout = (size_t)batch * C * Ho * Wo * Lo;
+  DevBuf di, d_o;
+  HIPCHK(di.alloc(nin * 8)); HIPCHK(d_o.alloc(nout * 8));
+  HIPCHK(hipMemcpy(di.p, in, nin * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_sum_pool, dim3(ew_grid(nout)), dim3(256), 0, ctx->stream, di.as<uint64_t>(), C, H, W, Li, (size_t)deff_in, K, Ho, Wo, d_o.as<uint64_t>(), Lo, nout);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(out, d_o.p, nout * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1306,9 +1443,19 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
   if (keys) {
     const size_t D = (size_t)s->D;
     // (the matrix-core key switch walks the key in steps of 64 rows: an effective dimension it cannot take is kept at full width)
-    auto clampd = [&](int d) { return (size_t)((d > 0 && (size_t)d < D && d % 64 == 0) ? d : D); };
+    // ... and the integer-VALU key switch (betak = 8, or a key the matrix-core tiling does not cover) walks whole rows of D words: a
+    // circuit that uses such a tier keeps every tensor at full width
+    bool all_mfma = true;
+    for (const Op& o : circ->ops) {
+      if (o.type != OP_LUT) continue;
+      all_mfma = all_mfma && keys->tiers[o.ip[4]].d_kskT != nullptr;
+      const int r = o.ip[9] ? 0 : o.ip[1];
+      const StepTiers stp = step_tiers_of(o);
+      for (int st_i = 0; st_i < r; st_i++) all_mfma = all_mfma && keys->tiers[stp.at(st_i)].d_kskT != nullptr;
+    }
+    auto clampd = [&](int d) { return (size_t)((all_mfma && d > 0 && (size_t)d < D && d % 64 == 0) ? d : D); };
     std::vector<char> known(nt, 0);
-    auto set = [&](int t, size_t deff, size_t width) { s->t_deff[t] = deff; s->t_L[t] = std::max(deff, width) + 1; known[t] = 1; };
+    auto set = [&](int t, size_t deff, size_t width) { s->t_deff[t] = deff; s->t_L[t] = (all_mfma ? std::max(deff, width) : D) + 1; known[t] = 1; };
     for (const Op& o : circ->ops)
       if (o.src0 == circ->input_tensor) { set(circ->input_tensor, clampd(o.ip[10]), 0); break; }
     if (!known[circ->input_tensor]) set(circ->input_tensor, D, 0);
@@ -1383,7 +1530,8 @@ extern "C" int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctf
 
 extern "C" int dctfhe_session_destroy(dctfhe_session* s) { delete s; return 0; }
 
-extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) {
+// host rows of `dim` mask words + body (dim = D: the full-width form; smaller: the compact wire form of dctfhe_encrypt_rows)
+extern "C" int dctfhe_session_upload_rows(dctfhe_session* s, const uint64_t* cts_in, int dim) {
   if (!s || !cts_in) return fail("dctfhe_session_upload: null argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->input_tensor;
@@ -1393,26 +1541,39 @@ extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) 
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
-  // host rows are D+1 words; the tensor is stored at its effective dimension.  The circuit was compiled for inputs that are
-  // zero beyond it (client encryption on a key prefix, dctfhe_params.input_dim): the key switch and the convolutions never
-  // look at that tail, so make sure it really is empty before dropping it
-  const size_t Lh = (size_t)s->D + 1, Ls = s->t_L[t], deff = s->t_deff[t];
+  if (dim < 1 || dim > s->D) return fail("dctfhe_session_upload: rows of %d mask words, the key has %d", dim, s->D);
+  // the tensor is stored at its effective dimension.  The circuit was compiled for inputs that are zero beyond it (client
+  // encryption on a key prefix, dctfhe_params.input_dim): the key switch and the convolutions never look at that tail, so make
+  // sure it really is empty before dropping it
+  const size_t Lh = (size_t)dim + 1, Ls = s->t_L[t], deff = s->t_deff[t];
   const size_t count = s->tensor_words[t] / Ls;
   DevBuf tmp;
   HIPCHK(tmp.alloc(count * Lh * 8));
   HIPCHK(hipMemcpyAsync(tmp.p, cts_in, count * Lh * 8, hipMemcpyHostToDevice, st));
-  if (deff < (size_t)s->D) {
+  if (deff < (size_t)dim) {
     HIPCHK(hipMemsetAsync(s->d_overflow, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_tail_nonzero, dim3(ew_grid(count * ((size_t)s->D - deff))), dim3(256), 0, st, tmp.as<uint64_t>(), count, s->D, (int)deff, s->d_overflow);
+    hipLaunchKernelGGL(k_tail_nonzero, dim3(ew_grid(count * ((size_t)dim - deff))), dim3(256), 0, st, tmp.as<uint64_t>(), count, dim, (int)deff, s->d_overflow);
     HIPCHK(hipGetLastError());
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, s->d_overflow, sizeof bad, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (bad) return fail("input ciphertexts have non-zero mask words beyond %zu: encrypt them with these parameters (input_dim)", deff);
   }
-  hipLaunchKernelGGL(k_restride, dim3(ew_grid(count * Ls)), dim3(256), 0, st, tmp.as<uint64_t>(), Lh, s->d_tensor[t], Ls, count, deff);
+  hipLaunchKernelGGL(k_restride, dim3(ew_grid(count * Ls)), dim3(256), 0, st, tmp.as<uint64_t>(), Lh, s->d_tensor[t], Ls, count, std::min(deff, (size_t)dim));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+extern "C" int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in) {
+  if (!s) return fail("dctfhe_session_upload: null argument");
+  return dctfhe_session_upload_rows(s, cts_in, s->D);
+}
+// mask words a compact row of the session's input / output needs (what upload_rows / download_rows accept as `dim` at least / at most
+// usefully); clear-mode sessions report 0
+extern "C" int dctfhe_session_dims(dctfhe_session* s, int* in_dim, int* out_dim) {
+  if (!s || !in_dim || !out_dim) return fail("dctfhe_session_dims: null argument");
+  *in_dim = s->keys ? (int)s->t_deff[s->circ->input_tensor] : 0;
+  *out_dim = s->keys ? (int)s->t_deff[s->circ->output_tensor] : 0;
   return 0;
 }
 extern "C" int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const double* sigma_per_op, int n_ops) {
@@ -1423,7 +1584,7 @@ extern "C" int dctfhe_session_set_noise(dctfhe_session* s, uint64_t seed, const 
   return 0;
 }
 
-extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
+extern "C" int dctfhe_session_download_rows(dctfhe_session* s, uint64_t* cts_out, int dim) {
   if (!s || !cts_out) return fail("dctfhe_session_download: null argument");
   HIPCHK(hipSetDevice(s->ctx->device));
   const int t = s->circ->output_tensor;
@@ -1433,15 +1594,20 @@ extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
-  const size_t Lh = (size_t)s->D + 1, Ls = s->t_L[t];
+  if (dim < (int)s->t_deff[t] || dim > s->D) return fail("dctfhe_session_download: rows of %d mask words; the output needs %zu and the key has %d", dim, s->t_deff[t], s->D);
+  const size_t Lh = (size_t)dim + 1, Ls = s->t_L[t];
   const size_t count = s->tensor_words[t] / Ls;
-  DevBuf tmp;      // back to host rows of D+1 words, zero tail
+  DevBuf tmp;      // to host rows of dim + 1 words, zero beyond the effective dimension
   HIPCHK(tmp.alloc(count * Lh * 8));
   hipLaunchKernelGGL(k_restride, dim3(ew_grid(count * Lh)), dim3(256), 0, st, s->d_tensor[t], Ls, tmp.as<uint64_t>(), Lh, count, s->t_deff[t]);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(cts_out, tmp.p, count * Lh * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return 0;
+}
+extern "C" int dctfhe_session_download(dctfhe_session* s, uint64_t* cts_out) {
+  if (!s) return fail("dctfhe_session_download: null argument");
+  return dctfhe_session_download_rows(s, cts_out, s->D);
 }
 
 extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
@@ -1507,9 +1673,17 @@ extern "C" int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing) {
           const uint64_t add = body_add + (approx ? (1ULL << (62 - p)) : (r > 0 ? (1ULL << (63 - p + r - 1)) : 0));
           int deff = (int)ds;
           if (steps > 0) {
-            deff = round_chain_deff(K, (int)ds, step_tiers_of(o), steps);
+            const StepTiers stp = step_tiers_of(o);
+            deff = round_chain_deff(K, (int)ds, stp, steps);
+            // the work row: the first deff mask words and the body.  What lies between deff and the end of the row is left alone when
+            // every key switch of the chain narrows to deff (the table bootstrap that ends the site rewrites the row); a key switch
+            // that cannot narrow reads the whole row, so those words are zeroed (they used to be whatever the recycled
+            // buffer held)
+            bool narrow = ks_narrows(K, tt, deff);
+            for (int st_i = 0; st_i < steps; st_i++) narrow = narrow && ks_narrows(K, stp.at(st_i), deff);
+            const size_t fill = narrow ? (size_t)deff : Ld - 1;
             const int h = tm.begin(CAT_LINEAR);
-            hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * ((size_t)deff + 1))), dim3(256), 0, st, src, Ls, ds, dst, Ld, E, (size_t)deff, shift, add);
+            hipLaunchKernelGGL(k_affine, dim3(ew_grid(E * (fill + 1))), dim3(256), 0, st, src, Ls, ds, dst, Ld, E, fill, shift, add);
             HIPCHK(hipGetLastError());
             tm.end(h);
           }

@@ -58,7 +58,7 @@ __device__ __forceinline__ int64_t gauss_torus(const rng_key& key, uint64_t stre
 }
 
 // stream ids.  Masks are drawn from the PUBLIC key at stream s, the matching noise from the SECRET key at stream s + 1.
-enum : uint64_t { STREAM_BIGKEY = 1, STREAM_SMALLKEY = 2, STREAM_PUBKEY = 3, STREAM_KSK = 16, STREAM_BSK_MASK = 64, STREAM_ENC = 256 };
+enum : uint64_t { STREAM_BIGKEY = 1, STREAM_SMALLKEY = 2, STREAM_PUBKEY = 3, STREAM_ENCKDF = 4, STREAM_KSK = 16, STREAM_BSK_MASK = 64, STREAM_ENC = 256 };
 
 __global__ void k_gen_bits(rng_key key, uint64_t stream, uint8_t* out, int len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,30 +81,32 @@ __device__ __forceinline__ uint64_t block_reduce_add(uint64_t v, uint64_t* red) 
 
 // ------------------------------------------------------------------------------------------ client
 // one block per ciphertext: a random on [0,dim_eff), b = <a,S> + phase + e
-__global__ void k_lwe_encrypt(const uint8_t* __restrict__ S, int D, int dim_eff, const uint64_t* __restrict__ phases,
+// Rows of `dim` mask words + the body (dim = D: the full-width form; dim < D: the compact wire form -- every mask word from dim_eff on
+// is zero anyway).  The draws are indexed as in the full-width form, so both forms of one call hold the same ciphertexts.
+__global__ void k_lwe_encrypt(const uint8_t* __restrict__ S, int D, int dim, int dim_eff, const uint64_t* __restrict__ phases,
                               double sigma, rng_key pub, rng_key sec, uint64_t stream, uint64_t* __restrict__ cts) {
   __shared__ uint64_t red[16];
   const size_t c = blockIdx.x;
-  uint64_t* ct = cts + c * (size_t)(D + 1);
+  uint64_t* ct = cts + c * (size_t)(dim + 1);
   uint64_t part = 0;
-  for (int j = threadIdx.x; j < D; j += blockDim.x) {
+  for (int j = threadIdx.x; j < dim; j += blockDim.x) {
     const uint64_t a = (j < dim_eff) ? rnd64(pub, stream, c * (uint64_t)(D + 1) + j) : 0;
     ct[j] = a;
     if (S[j]) part += a;
   }
   const uint64_t s = block_reduce_add(part, red);
-  if (threadIdx.x == 0) ct[D] = s + phases[c] + (uint64_t)gauss_torus(sec, stream + 1, c, sigma);
+  if (threadIdx.x == 0) ct[dim] = s + phases[c] + (uint64_t)gauss_torus(sec, stream + 1, c, sigma);
 }
 
-__global__ void k_lwe_phase(const uint8_t* __restrict__ S, int D, const uint64_t* __restrict__ cts, uint64_t* __restrict__ phases) {
+__global__ void k_lwe_phase(const uint8_t* __restrict__ S, int dim, const uint64_t* __restrict__ cts, uint64_t* __restrict__ phases) {
   __shared__ uint64_t red[16];
   const size_t c = blockIdx.x;
-  const uint64_t* ct = cts + c * (size_t)(D + 1);
+  const uint64_t* ct = cts + c * (size_t)(dim + 1);
   uint64_t part = 0;
-  for (int j = threadIdx.x; j < D; j += blockDim.x)
+  for (int j = threadIdx.x; j < dim; j += blockDim.x)
     if (S[j]) part += ct[j];
   const uint64_t s = block_reduce_add(part, red);
-  if (threadIdx.x == 0) phases[c] = ct[D] - s;
+  if (threadIdx.x == 0) phases[c] = ct[dim] - s;
 }
 
 // ------------------------------------------------------------------------------------------ keygen
@@ -418,7 +420,14 @@ struct pbs_launch {
   int pf_parts;               // 0: no L2 warm-up; else each workgroup touches 1/pf_parts of the next key rows
 };
 
-template <int LOGN, int K, int L, int P, int GROUPS, int MB = 0>
+// KLDS > 0: the GROUPS waves of a workgroup share each key tile through a ring of KLDS tiles in LDS (pbs_core.h, pbs_thread)
+template <int LOGN, int K, int L, int P, int MB, int KLDS>
+constexpr size_t pbs_lds_bytes(int groups) {
+  using G = pbs_geom<LOGN, K, L, P, MB>;
+  return (size_t)G::TW_BYTES + (size_t)groups * G::GROUP_BYTES + (size_t)KLDS * 3 * (K + 1) * G::T * 16;
+}
+
+template <int LOGN, int K, int L, int P, int GROUPS, int MB = 0, int KLDS = 0>
 __global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P, MB>::T * GROUPS), ((P >= 16 || (pbs_geom<LOGN, K, L, P, MB>::T * GROUPS) >= 512) ? 1 : 2))
 pbs_kernel(pbs_launch a) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
@@ -461,6 +470,9 @@ pbs_kernel(pbs_launch a) {
   A.zlut = MB ? tw + G::TW_LDS_ELEMS : nullptr;
   if constexpr (G::TWIST_LDS) A.twist = tw + G::F::TW_TOTAL; else A.twist = a.tw + G::F::TW_TOTAL;
   A.pf_rank = (int)((blockIdx.x / 8) % (unsigned)(a.pf_parts > 0 ? a.pf_parts : 1));   // blocks b and b+8 share an XCD (round-robin dispatch; speed only)
+  A.kring = reinterpret_cast<const cplx*>(per_group + (size_t)GROUPS * G::GROUP_BYTES);
+  A.kring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(per_group + (size_t)GROUPS * G::GROUP_BYTES);
+  A.kwave = g;
 #if defined(DCTFHE_ABLATE_BARRIER)   // timing experiments only (tools/exp_pbs.hip): no workgroup barriers, wrong results
   if constexpr (true) {
 #else
@@ -468,8 +480,9 @@ pbs_kernel(pbs_launch a) {
 #endif
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
     // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
-    pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P, MB, KLDS, GROUPS>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
   } else {
+    static_assert(KLDS == 0 || T <= 64, "key tiles through LDS: one wave per ciphertext");
     pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
   }
 }
@@ -612,7 +625,7 @@ k_conv2d_mfma(const uint64_t* __restrict__ in, int H, int W, size_t Lin, size_t 
 }
 
 // any non-zero mask word in [deff, D) of `count` ciphertexts?  (guards the effective-dimension shortcut at the session input)
-__global__ void k_tail_nonzero(const uint64_t* __restrict__ cts, size_t count, int D, int deff, int* __restrict__ flag) {
+__global__ void k_tail_nonzero(const uint64_t* __restrict__ cts, size_t count, int D /* mask words per row */, int deff, int* __restrict__ flag) {
   const size_t tail = (size_t)(D - deff), total = count * tail;
   int bad = 0;
   for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x)
@@ -718,16 +731,60 @@ struct dct_args {
   int n[3];                     // kept coefficients per plane
   const int32_t* idx[3];        // their row-major indices u*fs + v
   const float *mean, *stdv;     // per output channel
-  int round_coeffs;             // JPEG-domain path: coefficients are quantised (round half away from zero) and the up-sampled
-                                // planes rounded half to even, as the int16 arrays of the reference are
+  int round_coeffs;             // JPEG-domain path (block size 8): coefficients are libjpeg's quantised integers (integer islow DCT, quality-100
+                                // tables) and the up-sampled planes are rounded half to even, as the int16 arrays of the reference are
   float* out;                   // [B][n0+n1+n2][S][S]
   int batch;
 };
+
+// libjpeg's accurate integer forward DCT ("islow": Loeffler-Ligtenberg-Moschytz, 13-bit constants, 2 extra bits carried out of the row
+// pass; jfdctint.c [K: restated from the published algorithm -- libjpeg-turbo is not in this environment, PARITY UNPINNED]) on one row
+// or column of 8 values, in place.  TurboJPEG picks this method at quality >= 96 (reference data/cvfunctional.py:24: quality=100).
+// first = 1: row pass (outputs scaled by 2^2 * sqrt(8)); first = 0: column pass (removes the 2^2; the 2-D result is 8x the DCT).
+__host__ __device__ inline void jfdct_islow_1d(int32_t* d, int first) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+                    F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+  auto descale = [](int32_t x, int n) { return (x + (1 << (n - 1))) >> n; };
+  int32_t t0 = d[0] + d[7], t7 = d[0] - d[7], t1 = d[1] + d[6], t6 = d[1] - d[6], t2 = d[2] + d[5], t5 = d[2] - d[5], t3 = d[3] + d[4], t4 = d[3] - d[4];
+  const int32_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  const int sh = first ? CB - P1 : CB + P1;
+  d[0] = first ? (t10 + t11) << P1 : descale(t10 + t11, P1);
+  d[4] = first ? (t10 - t11) << P1 : descale(t10 - t11, P1);
+  int32_t z1 = (t12 + t13) * F0_541;
+  d[2] = descale(z1 + t13 * F0_765, sh);
+  d[6] = descale(z1 - t12 * F1_847, sh);
+  z1 = t4 + t7;
+  int32_t z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int32_t z5 = (z3 + z4) * F1_175;
+  t4 *= F0_298; t5 *= F2_053; t6 *= F3_072; t7 *= F1_501;
+  z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+  z3 += z5; z4 += z5;
+  d[7] = descale(t4 + z1 + z3, sh);
+  d[5] = descale(t5 + z2 + z4, sh);
+  d[3] = descale(t6 + z2 + z3, sh);
+  d[1] = descale(t7 + z1 + z4, sh);
+}
+// quantised coefficient (u, v) of 8x8 block (by, bx): level shift, islow DCT, division by 8 * q with q = 1 (the quality-100 tables are
+// all ones), rounded half away from zero as libjpeg's quantiser does (jcdctmgr.c)
+__device__ inline int32_t jpeg_islow_coeff(const uint8_t* plane, int side, int by, int bx, int u, int v) {
+  int32_t col[8];
+  for (int i = 0; i < 8; i++) {
+    int32_t row[8];
+    for (int j = 0; j < 8; j++) row[j] = (int32_t)plane[(size_t)(by * 8 + i) * side + bx * 8 + j] - 128;
+    jfdct_islow_1d(row, 1);
+    col[i] = row[v];
+  }
+  jfdct_islow_1d(col, 0);
+  const int32_t c = col[u];
+  return c < 0 ? -((-c + 4) >> 3) : (c + 4) >> 3;
+}
 
 __device__ __forceinline__ double dct_basis(int fs, int u, int j) {
   return u == 0 ? rsqrt((double)fs) : sqrt(2.0 / fs) * cospi((double)((2 * j + 1) * u) / (double)(2 * fs));
 }
 __device__ inline double dct_coeff(const uint8_t* plane, int side, int fs, int by, int bx, int u, int v, int round_coeffs) {
+  if (round_coeffs && fs == 8) return (double)jpeg_islow_coeff(plane, side, by, bx, u, v);     // the JPEG-domain path: integers throughout
   double acc = 0.0;
   for (int i = 0; i < fs; i++) {
     double row = 0.0;

@@ -210,6 +210,9 @@ struct pbs_args {
   const cplx* zlut;           // MB, device: the same roots as two LDS tables, lo[2^ZLO] then hi[2^ZHI] (nullptr: gather from wtab)
   const cplx* twist;          // the T twist bases e^{i pi t/N} (entries TW_TOTAL.. of the twiddle table; LDS or global)
   int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
+  const cplx* kring;          // KLDS: ring of key tiles in LDS shared by the KW waves of the workgroup (generic pointer for the reads)
+  uint32_t kring_lds;         // ... its LDS byte address (what the LDS-DMA instruction takes in M0)
+  int kwave;                  // ... this wave's index among the KW
 };
 
 // The whole bootstrap for one ciphertext, executed by thread t of its group.
@@ -221,7 +224,15 @@ struct pbs_args {
 // PAIR of key bits, no rotation through LDS -- and the monomials act in the Fourier domain, where X^e is the pointwise
 // factor zeta^e, zeta = e^{i pi (1-4k)/N} the evaluation point (spectrum_freq).  Price: three key blocks per pair
 // instead of two, and the key/FFT noise of three products scaled by |X^e - 1|^2 = 2 (dctfhe/params.py prices it).
-template <int LOGN, int K, int L, int P, int MB = 0, class Sync, class WSync>
+// KLDS > 0 (device, general two-bit form, one wave per ciphertext): the KW waves of a workgroup -- KW ciphertexts -- walk the key in
+// lock-step and share every key tile through LDS: each (gadget row, point j) step of 3 (K+1) key vectors is fetched ONCE per workgroup
+// by LDS-DMA (global_load_lds_dwordx4: every wave brings 1/KW of it, no registers), KLDS - 1 steps ahead into a ring of KLDS tiles,
+// and read by all KW waves with ds_read_b128.  Without it every wave pulls its own copy of the same lines through the CU's vector L1
+// (64 B/clk): 8 waves x 221 KB per iteration on the k = 2 one-level tier, the path that kernel saturated (profiles/r02_exp_ablations.log).
+// Protocol per step s: wait until this wave's DMAs of step s have landed (counted vmcnt: the younger ones stay in flight), workgroup
+// barrier (=> everybody's part of step s is there, and everybody is done reading step s - 1), issue the DMAs of step s + KLDS - 1 into
+// the tile step s - 1 used, read step s.
+template <int LOGN, int K, int L, int P, int MB = 0, int KLDS = 0, int KW = 1, class Sync, class WSync>
 HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw, cplx* exch, uint64_t* accl_raw, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
@@ -272,13 +283,53 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 
   // MB: root exponent (1 - 4k) mod 2N of this thread's first point in each small transform of the last pass; point j' of
   // small transform g sits at exponent ulow[g] - j' * (2N / RL)
-  uint32_t ulow[G::NG];
-  if constexpr (MB) {
-    static_for<0, G::NG>([&](auto Gg) {
-      constexpr int g = decltype(Gg)::value;
-      ulow[g] = (uint32_t)(1 - 4 * spectrum_freq<G::LOGM, P>(P * t + g * G::RL)) & (2 * N - 1);
+  // -- ONE value per thread: small transform g starts NG*t + g in the digit of the second-last pass (no carry: NG*t is a multiple
+  // of NG), whose frequency weight is M / (P * RL), so ulow[g] = ulow0 - g * USTEP.  (Holding all NG of them cost the general
+  // three-level kernel four spilled registers, reloaded through the same in-order vmcnt queue as its key loads.)
+  uint32_t ulow0 = 0;
+  constexpr uint32_t USTEP = 4u * (uint32_t)(M / (P * G::RL));
+  if constexpr (MB) ulow0 = (uint32_t)(1 - 4 * spectrum_freq<G::LOGM, P>(P * t)) & (2 * N - 1);
+
+#if defined(DCTFHE_DEVICE)
+  constexpr bool KL = KLDS > 0;
+#else
+  constexpr bool KL = false;       // the host emulator reads the key where it lies
+#endif
+  constexpr int K_SPI = G::ROWS * P;                       // steps (gadget row, point j) per iteration
+  constexpr int K_STEP = 3 * (K + 1) * T;                  // complex values per step: blocks w x output polynomials q x T lanes
+  constexpr int K_LPW = KL ? 3 * (K + 1) * 64 / KW : 64;   // 16-byte lanes per wave and step
+  constexpr int K_CH = (K_LPW + 63) / 64, K_CHL = K_LPW / K_CH;       // DMA instructions per wave and step, active lanes in each
+  static_assert(!KL || (MB && !G::PAIR && L == 1 && T == 64 && KLDS >= 2 && (3 * (K + 1) * 64) % KW == 0 && K_LPW % K_CH == 0 && K_SPI % KLDS == 0),
+                "key tiles through LDS: general two-bit form, one wave per ciphertext, tile count divides the steps per iteration");
+  uint32_t koff[K_CH];       // byte offset of this lane's 16 bytes of chunk i inside a pair's key, without the step's (row, j) part
+#if defined(DCTFHE_DEVICE)
+  [[maybe_unused]] const uint32_t kwave = KL ? DCTFHE_UNIFORM(A.kwave) : 0;
+  [[maybe_unused]] auto kissue = [&](const cplx* key_pair /* wave-uniform */, auto RowJ, auto Buf) {
+    constexpr int s = decltype(RowJ)::value, row = s / P, j = s % P, buf = decltype(Buf)::value;
+    const uint64_t base = (uint64_t)(key_pair + ((size_t)row * (K + 1) * M + (size_t)j * T));
+    static_for<0, K_CH>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const uint32_t dst = A.kring_lds + (uint32_t)((buf * K_STEP + (int)(kwave * K_CH + i) * K_CHL) * 16);
+      const uint64_t mask = K_CHL >= 64 ? ~0ull : ((1ull << K_CHL) - 1);
+      uint32_t keep_m0; uint64_t keep_exec;
+      const uint32_t vo = koff[i];
+      const uint64_t sb = base;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, %5\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(vo), "s"(sb), "s"(dst), "s"(mask) : "memory");
     });
+  };
+  if constexpr (KL) {
+    static_for<0, K_CH>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const uint32_t pos = (kwave * K_CH + i) * K_CHL + (uint32_t)t;          // 16-byte slot of this lane in the step's tile (t < K_CHL)
+      const uint32_t vi = pos / 64, tt = pos % 64, w = vi / (K + 1), q = vi % (K + 1);
+      koff[i] = ((w * G::ROWS * (K + 1) + q) * M + tt) * 16;
+    });
+    // steps 0 .. KLDS-2 of the first iteration
+    static_for<0, KLDS - 1>([&](auto S) { kissue(make_uniform(A.bsk), S, S); });
   }
+#endif
 
   // zeta^m: on the device the product of the two LDS tables, on the host emulator (zlut == nullptr) the full table
   auto zeta = [&](uint32_t m) -> cplx {
@@ -300,6 +351,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
       // ever touched by their owner here -- there is no rotation -- so no barrier guards them.
       const uint32_t a2 = (uint32_t)(((A.ct_small[i + 1] >> msh) + 1) >> 1) & (2 * N - 1);
       const uint32_t au = DCTFHE_UNIFORM(a), a2u = DCTFHE_UNIFORM(a2);
+      const uint32_t e1 = a * ulow0, e2 = a2 * ulow0;
       const cplx* key = A.bsk + (size_t)(3 * (i >> 1)) * G::BSK_ELEMS_PER_KEYBIT;
       static_for<0, K + 1>([&](auto Pp) {
         constexpr int p = decltype(Pp)::value;
@@ -333,8 +385,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             constexpr int j = decltype(J)::value;
             constexpr int g = j / G::RL, jp = j % G::RL;
             if constexpr (jp == 0) {
-              zb1 = zeta((a * ulow[g]) & (2 * N - 1));
-              zb2 = zeta((a2 * ulow[g]) & (2 * N - 1));
+              zb1 = zeta((e1 - au * (USTEP * (uint32_t)g)) & (2 * N - 1));      // a * ulow[g]; the second product is wave-uniform
+              zb2 = zeta((e2 - a2u * (USTEP * (uint32_t)g)) & (2 * N - 1));
             }
             cplx z1 = zb1, z2 = zb2;
             if constexpr (jp > 0) {
@@ -342,6 +394,24 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
               z2 = cmul(z2, root8((0u - a2u * (uint32_t)jp) * (8 / G::RL)));
             }
             cplx kk[3][K + 1];
+#if defined(DCTFHE_DEVICE)
+            if constexpr (KL) {
+              constexpr int s = row * P + j, ahead = s + KLDS - 1;
+              // this wave's DMAs of step s have landed when at most those of the KLDS - 2 younger steps are outstanding; its own
+              // reads of step s - 1 are over (lgkmcnt) before anybody may overwrite that tile
+              asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((KLDS - 2) * K_CH) : "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+              kissue(make_uniform(key + (ahead >= K_SPI ? (size_t)3 * G::BSK_ELEMS_PER_KEYBIT : 0)), std::integral_constant<int, ahead % K_SPI>{},
+                     std::integral_constant<int, ahead % KLDS>{});
+              const cplx* tile = A.kring + (s % KLDS) * K_STEP;
+              static_for<0, 3>([&](auto Ww) {
+                constexpr int w = decltype(Ww)::value;
+                static_for<0, K + 1>([&](auto Q) { constexpr int q = decltype(Q)::value; kk[w][q] = tile[(w * (K + 1) + q) * 64 + t]; });
+              });
+            } else
+#endif
+            {
             static_for<0, 3>([&](auto Ww) {
               constexpr int w = decltype(Ww)::value;
               static_for<0, K + 1>([&](auto Q) {
@@ -353,6 +423,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
 #endif
               });
             });
+            }
             DCTFHE_SCHED_BARRIER();
             const cplx m1 = cmk(z1.re - 1.0, z1.im), m2 = cmk(z2.re - 1.0, z2.im);
             cplx m12 = cmul(z1, z2); m12.re -= 1.0;
@@ -384,13 +455,14 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
       // -- a factor that only depends on a (the same for the whole ciphertext), read from the 8-entry table below.
       // (a wave holds threads of one ciphertext only: T >= 64 on the device)
       const uint32_t au = DCTFHE_UNIFORM(a), a2u = DCTFHE_UNIFORM(a2);
+      const uint32_t e1 = a * ulow0, e2 = a2 * ulow0;
       cplx zb1 = cmk(1.0, 0.0), zb2 = cmk(1.0, 0.0);
       static_for<0, P>([&](auto J) {
         constexpr int j = decltype(J)::value;
         constexpr int g = j / G::RL, jp = j % G::RL;
         if constexpr (jp == 0) {
-          zb1 = zeta((a * ulow[g]) & (2 * N - 1));
-          zb2 = zeta((a2 * ulow[g]) & (2 * N - 1));
+          zb1 = zeta((e1 - au * (USTEP * (uint32_t)g)) & (2 * N - 1));
+          zb2 = zeta((e2 - a2u * (USTEP * (uint32_t)g)) & (2 * N - 1));
         }
         cplx z1 = zb1, z2 = zb2;
         if constexpr (jp > 0) {
@@ -583,6 +655,9 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
     });
   }
 
+#if defined(DCTFHE_DEVICE)
+  if constexpr (KL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tiles fetched ahead of the last step (key padding) land before the wave ends
+#endif
   // sample extract (coefficient 0) straight into the output LWE ciphertext
   uint64_t* o = A.out;
   static_for<0, K>([&](auto Pp) {

@@ -17,7 +17,7 @@ MAX_TIERS = 12
 class Tier(C.Structure):
     _fields_ = [("n", C.c_int32), ("k", C.c_int32), ("logN", C.c_int32), ("l", C.c_int32), ("beta", C.c_int32),
                 ("lk", C.c_int32), ("betak", C.c_int32), ("ksk_share", C.c_int32),
-                ("unroll", C.c_int32), ("reserved", C.c_int32),
+                ("unroll", C.c_int32), ("key_lds", C.c_int32),
                 ("lwe_sigma", C.c_double), ("glwe_sigma", C.c_double)]
 
 
@@ -42,10 +42,10 @@ EXPORTS = [
     "dctfhe_last_error", "dctfhe_version", "dctfhe_ctx_create", "dctfhe_ctx_destroy", "dctfhe_ctx_set_stream",
     "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_client_key_create", "dctfhe_client_key_destroy", "dctfhe_eval_keys_generate",
     "dctfhe_eval_keys_destroy", "dctfhe_eval_keys_export", "dctfhe_eval_keys_import", "dctfhe_client_key_export_secret",
-    "dctfhe_eval_keys_export_ksk", "dctfhe_client_key_export_bsk", "dctfhe_rng_host", "dctfhe_rng_device", "dctfhe_client_key_set_encrypt_counter", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
-    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_circuit_load", "dctfhe_circuit_destroy", "dctfhe_params_check", "dctfhe_circuit_validate", "dctfhe_dct_frontend",
+    "dctfhe_eval_keys_export_ksk", "dctfhe_client_key_export_bsk", "dctfhe_rng_host", "dctfhe_rng_device", "dctfhe_client_key_set_encrypt_counter", "dctfhe_client_key_set_encrypt_nonce", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_encrypt_rows", "dctfhe_decrypt_rows", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
+    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_add_rows", "dctfhe_affine_rows", "dctfhe_sum_pool_rows", "dctfhe_circuit_load", "dctfhe_circuit_destroy", "dctfhe_params_check", "dctfhe_circuit_validate", "dctfhe_dct_frontend",
     "dctfhe_circuit_stats", "dctfhe_circuit_io", "dctfhe_session_create", "dctfhe_session_destroy",
-    "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
+    "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_session_upload_rows", "dctfhe_session_download_rows", "dctfhe_session_dims", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
 ]
 
 _lib = None
@@ -83,14 +83,20 @@ def load():
     L.dctfhe_rng_host.argtypes = [C.c_char_p, u64, u64, sz, vp]
     L.dctfhe_rng_device.argtypes = [vp, C.c_char_p, u64, u64, sz, vp]
     L.dctfhe_client_key_set_encrypt_counter.argtypes = [vp, u64]
+    L.dctfhe_client_key_set_encrypt_nonce.argtypes = [vp, C.c_char_p]
     L.dctfhe_encrypt.argtypes = [vp, vp, vp, sz, vp]
     L.dctfhe_decrypt.argtypes = [vp, vp, vp, sz, vp]
+    L.dctfhe_encrypt_rows.argtypes = [vp, vp, vp, sz, i32, vp]
+    L.dctfhe_decrypt_rows.argtypes = [vp, vp, vp, sz, i32, vp]
     L.dctfhe_keyswitch.argtypes = [vp, vp, i32, vp, sz, i32, vp]
     L.dctfhe_session_set_noise.argtypes = [vp, C.c_uint64, vp, i32]
     L.dctfhe_keyswitch_prefix.argtypes = [vp, vp, i32, vp, sz, i32, i32, vp]
     L.dctfhe_pbs.argtypes = [vp, vp, i32, vp, sz, vp, i32, i32, vp, vp]
     L.dctfhe_round_lut.argtypes = [vp, vp, i32, i32, vp, sz, i32, i32, vp, i32, i32, vp, vp]
     L.dctfhe_conv2d.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp]
+    L.dctfhe_add_rows.argtypes = [vp, vp, i32, i32, vp, i32, i32, sz, i32, vp]
+    L.dctfhe_affine_rows.argtypes = [vp, vp, i32, i32, sz, i32, i32, u64, i32, vp]
+    L.dctfhe_sum_pool_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.dctfhe_dct_frontend.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, vp]
     L.dctfhe_params_check.argtypes = [C.POINTER(Params)]
     L.dctfhe_circuit_validate.argtypes = [vp, sz]
@@ -103,6 +109,9 @@ def load():
     L.dctfhe_session_upload.argtypes = [vp, vp]
     L.dctfhe_session_run.argtypes = [vp, C.POINTER(Timing)]
     L.dctfhe_session_download.argtypes = [vp, vp]
+    L.dctfhe_session_upload_rows.argtypes = [vp, vp, i32]
+    L.dctfhe_session_download_rows.argtypes = [vp, vp, i32]
+    L.dctfhe_session_dims.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dctfhe_fp64_peak.argtypes = [vp, C.POINTER(C.c_double)]
     L.dctfhe_bench_pbs.argtypes = [vp, vp, i32, sz, i32, C.POINTER(C.c_double)]
     _lib = L

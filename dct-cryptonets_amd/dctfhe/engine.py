@@ -10,12 +10,12 @@ from ._lib import Params, Stats, Tier, Timing, check, ptr
 
 
 def make_params(D, n_max, tiers, input_sigma, input_dim=0):
-    """tiers: list of dicts with n,k,logN,l,beta,lk,betak,lwe_sigma,glwe_sigma[,ksk_share][,unroll]."""
+    """tiers: list of dicts with n,k,logN,l,beta,lk,betak,lwe_sigma,glwe_sigma[,ksk_share][,unroll][,key_lds]."""
     p = Params()
     p.D, p.n_max, p.n_tiers, p.input_sigma, p.input_dim = D, n_max, len(tiers), input_sigma, input_dim
     for i, t in enumerate(tiers):
         p.tiers[i] = Tier(t["n"], t["k"], t["logN"], t["l"], t["beta"], t["lk"], t["betak"], t.get("ksk_share", -1),
-                          t.get("unroll", 1), 0, t["lwe_sigma"], t["glwe_sigma"])
+                          t.get("unroll", 1), t.get("key_lds", 0), t["lwe_sigma"], t["glwe_sigma"])
     return p
 
 
@@ -47,6 +47,27 @@ class Context:
         out = np.empty((B, C_, S, S), np.float32)
         check(self.L.dctfhe_dct_frontend(self.h, ptr(y), ptr(c1), ptr(c2), B, S, Sc, fs, ptr(ii[0]), ii[0].size, ptr(ii[1]), ii[1].size,
                                          ptr(ii[2]), ii[2].size, ptr(mean), ptr(std), int(bool(round_coeffs)), ptr(out)))
+        return out
+
+    def add_rows(self, a, deff_a, b, deff_b, dim_o):
+        """rows [count, dim + 1] at effective dimensions deff_* -> a + b as rows [count, dim_o + 1] (include/dctfhe.h dctfhe_add_rows)"""
+        a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
+        out = np.empty((a.shape[0], dim_o + 1), np.uint64)
+        check(self.L.dctfhe_add_rows(self.h, ptr(a), a.shape[1] - 1, deff_a, ptr(b), b.shape[1] - 1, deff_b, a.shape[0], dim_o, ptr(out)))
+        return out
+
+    def affine_rows(self, a, deff_a, inout, nwords, shift, body_add):
+        a = np.ascontiguousarray(a, np.uint64)
+        out = np.ascontiguousarray(inout, np.uint64).copy()
+        check(self.L.dctfhe_affine_rows(self.h, ptr(a), a.shape[1] - 1, deff_a, a.shape[0], nwords, shift, C.c_uint64(body_add), out.shape[1] - 1, ptr(out)))
+        return out
+
+    def sum_pool_rows(self, x, deff, K, dim_o):
+        """x [batch, C, H, W, dim + 1] -> [batch, C, H // K, W // K, dim_o + 1]"""
+        x = np.ascontiguousarray(x, np.uint64)
+        B, Cc, H, W, L = x.shape
+        out = np.empty((B, Cc, H // K, W // K, dim_o + 1), np.uint64)
+        check(self.L.dctfhe_sum_pool_rows(self.h, ptr(x), L - 1, deff, B, Cc, H, W, K, dim_o, ptr(out)))
         return out
 
     def conv2d(self, D, cts, batch, Cin, H, W, weight, stride, pad):
@@ -112,19 +133,34 @@ class ClientKey:
         return out
 
     def set_encrypt_counter(self, next_call):
-        """processes that share this key (ranks of one job) take disjoint ranges, e.g. rank << 32"""
+        """position inside this handle's own encryption streams (handles already differ by their nonce: include/dctfhe.h)"""
         check(self.L.dctfhe_client_key_set_encrypt_counter(self.h, next_call))
 
-    def encrypt(self, phases):
+    def set_encrypt_nonce(self, nonce16):
+        """FIX the 128-bit encryption nonce the handle drew from the OS -- reproducible tests / experiments only"""
+        nonce16 = bytes(nonce16)
+        if len(nonce16) != 16:
+            raise ValueError("an encryption nonce is exactly 16 bytes")
+        check(self.L.dctfhe_client_key_set_encrypt_nonce(self.h, nonce16))
+
+    @property
+    def input_dim(self):
+        """mask words of a fresh encryption (the compact row width of a circuit input)"""
+        return self.params.input_dim or self.params.D
+
+    def encrypt(self, phases, dim=None):
+        """-> rows of dim mask words + body; dim None: the full-width form (D + 1 words), dim = self.input_dim: the compact wire form"""
         phases = np.ascontiguousarray(phases, np.uint64).reshape(-1)
-        out = np.empty((phases.size, self.D + 1), np.uint64)
-        check(self.L.dctfhe_encrypt(self.ctx.h, self.h, ptr(phases), phases.size, ptr(out)))
+        dim = self.D if dim is None else int(dim)
+        out = np.empty((phases.size, dim + 1), np.uint64)
+        check(self.L.dctfhe_encrypt_rows(self.ctx.h, self.h, ptr(phases), phases.size, dim, ptr(out)))
         return out
 
-    def decrypt(self, cts):
-        cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, self.D + 1)
+    def decrypt(self, cts, dim=None):
+        dim = self.D if dim is None else int(dim)
+        cts = np.ascontiguousarray(cts, np.uint64).reshape(-1, dim + 1)
         out = np.empty(cts.shape[0], np.uint64)
-        check(self.L.dctfhe_decrypt(self.ctx.h, self.h, ptr(cts), cts.shape[0], ptr(out)))
+        check(self.L.dctfhe_decrypt_rows(self.ctx.h, self.h, ptr(cts), cts.shape[0], dim, ptr(out)))
         return out
 
     def close(self):
@@ -221,7 +257,7 @@ class Keys:
         return self.params.tiers[i]
 
     def __getattr__(self, name):
-        if name in ("export_secret", "export_bsk", "encrypt", "decrypt", "seed"):
+        if name in ("export_secret", "export_bsk", "encrypt", "decrypt", "seed", "input_dim", "set_encrypt_nonce", "set_encrypt_counter"):
             return getattr(self.client, name)
         if name in ("export_ksk", "keyswitch", "pbs", "round_lut", "bench_pbs", "to_blob"):
             return getattr(self.eval, name)
@@ -264,10 +300,21 @@ class Session:
         self.h = C.c_void_p()
         check(self.L.dctfhe_session_create(ctx.h, circuit.h, keys.h if keys is not None else None, batch, C.byref(self.h)))
 
-    def upload(self, cts):
+    def dims(self):
+        """(input, output) effective dimensions: the compact row widths of this session's circuit (0, 0 in clear mode)"""
+        a, b = C.c_int(), C.c_int()
+        check(self.L.dctfhe_session_dims(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def upload(self, cts, dim=None):
+        """dim None: rows of D + 1 words (1 in clear mode); else the compact wire form, rows of dim mask words + body"""
         cts = np.ascontiguousarray(cts, np.uint64)
-        assert cts.size == self.batch * self.circuit.n_in * self.words, (cts.shape, self.batch, self.circuit.n_in, self.words)
-        check(self.L.dctfhe_session_upload(self.h, ptr(cts)))
+        words = self.words if (dim is None or self.keys is None) else dim + 1
+        assert cts.size == self.batch * self.circuit.n_in * words, (cts.shape, self.batch, self.circuit.n_in, words)
+        if dim is None or self.keys is None:
+            check(self.L.dctfhe_session_upload(self.h, ptr(cts)))
+        else:
+            check(self.L.dctfhe_session_upload_rows(self.h, ptr(cts), int(dim)))
 
     def set_noise(self, seed, sigma_per_op):
         """clear-mode sessions: `simulate` with the noise model (sigma per op, fraction of the torus); None switches it off"""
@@ -282,9 +329,13 @@ class Session:
         check(self.L.dctfhe_session_run(self.h, C.byref(t) if timing else None))
         return t
 
-    def download(self):
-        out = np.empty((self.batch, self.circuit.n_out, self.words), np.uint64)
-        check(self.L.dctfhe_session_download(self.h, ptr(out)))
+    def download(self, dim=None):
+        if dim is None or self.keys is None:
+            out = np.empty((self.batch, self.circuit.n_out, self.words), np.uint64)
+            check(self.L.dctfhe_session_download(self.h, ptr(out)))
+        else:
+            out = np.empty((self.batch, self.circuit.n_out, dim + 1), np.uint64)
+            check(self.L.dctfhe_session_download_rows(self.h, ptr(out), int(dim)))
         return out
 
     def close(self):

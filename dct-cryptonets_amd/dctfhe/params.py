@@ -30,6 +30,7 @@ class TierSpec:
     betak: int
     ksk_share: int = -1
     unroll: int = 1            # key bits per blind-rotate iteration (2: two-bit rotation, csrc/pbs_core.h; k = 1, l = 1 only)
+    key_lds: int = 0           # 1: bootstrap-key tiles shared by the waves of a workgroup through LDS (Ba2's geometry only; no faster: DESIGN 5)
     lwe_sigma: float = 0.0
     glwe_sigma: float = 0.0
 

@@ -52,33 +52,19 @@ class FHECircuit:
         broadcast key seed; int = deterministic test seed (dctfhe.engine.seed_bytes)."""
         self._o._keygen(seed, force)
 
-    @property
-    # -- client / server split (reference homomorphic_eval.py:313-317 keeps both halves in one process) ------------
+    # -- client / server split: the owner's methods (QuantizedModule) -----------------------------------------------
     def export_evaluation_keys(self):
-        """client side: the evaluation keys as a flat uint8 blob to ship to the server (no secret inside)"""
-        if self._keys is None:
-            self._keygen(None)
-        return self._keys.eval.to_blob()
+        return self._o.export_evaluation_keys()
 
     def load_evaluation_keys(self, blob):
-        """server side: evaluate with keys a client generated elsewhere; this module can then run `evaluate_encrypted`
-        but can neither encrypt nor decrypt"""
-        from .engine import EvalKeys
-        ctx = self._context()
-        for k in [k for k in self._sessions if k[0] == "execute"]:
-            self._sessions.pop(k).close()
-        if self._keys is not None:
-            self._keys.close()
-        self._keys = EvalKeys.from_blob(ctx, blob)
+        return self._o.load_evaluation_keys(blob)
 
-    def evaluate_encrypted(self, cts, batch):
-        """server side: input ciphertexts [batch * n_in, D+1] -> output ciphertexts [batch * n_out, D+1]"""
-        sess = self._session("execute", batch)
-        sess.upload(cts)
-        sess.run()
-        return sess.download().reshape(-1, self._keys.D + 1)
+    def evaluate_encrypted(self, cts, batch, dim=None):
+        return self._o.evaluate_encrypted(cts, batch, dim)
 
+    @property
     def statistics(self):
+        """Concrete's `fhe_circuit.statistics` is a property; here the engine's dctfhe_stats of the compiled circuit"""
         return self._o.statistics()
 
 
@@ -93,6 +79,7 @@ class QuantizedModule:
         self._sessions = {}
         self.fhe_circuit = FHECircuit(self)
         self.last_timing = None
+        self.last_io = None
         self.sim_seed = 977
 
     # -- lazy device objects -------------------------------------------------------------
@@ -139,12 +126,16 @@ class QuantizedModule:
             self._keys.close()
         self._keys = EvalKeys.from_blob(ctx, blob)
 
-    def evaluate_encrypted(self, cts, batch):
-        """server side: input ciphertexts [batch * n_in, D+1] -> output ciphertexts [batch * n_out, D+1]"""
+    def evaluate_encrypted(self, cts, batch, dim=None):
+        """server side: input ciphertexts [batch * n_in, D+1] -> output ciphertexts [batch * n_out, D+1]; dim: the compact wire
+        form instead -- input rows of dim mask words + body, output rows of Session.dims()[1] mask words + body"""
         sess = self._session("execute", batch)
-        sess.upload(cts)
+        sess.upload(cts, dim)
         sess.run()
-        return sess.download().reshape(-1, self._keys.D + 1)
+        if dim is None:
+            return sess.download().reshape(-1, self._keys.D + 1)
+        out_dim = sess.dims()[1]
+        return sess.download(out_dim).reshape(-1, out_dim + 1)
 
     def statistics(self):
         self._context()
@@ -191,11 +182,21 @@ class QuantizedModule:
                 sess.set_noise(0, None)
         t0 = time.time()
         if mode == "execute":
-            cts = self._keys.encrypt(phases.reshape(-1))
-            sess.upload(cts)
+            # ciphertexts travel in the compact wire form: a fresh encryption masks input_dim words, an output the ring of the last
+            # table tier -- not the D words of the master key (include/dctfhe.h dctfhe_encrypt_rows)
+            in_dim, out_dim = sess.dims()
+            t1 = time.time()
+            cts = self._keys.encrypt(phases.reshape(-1), in_dim)
+            t2 = time.time()
+            sess.upload(cts, in_dim)
+            t3 = time.time()
             timing = sess.run(timing=True)
-            out = sess.download().reshape(-1, self._keys.D + 1)
-            out_ph = self._keys.decrypt(out).reshape(B, -1)
+            t4 = time.time()
+            out = sess.download(out_dim).reshape(-1, out_dim + 1)
+            t5 = time.time()
+            out_ph = self._keys.decrypt(out, out_dim).reshape(B, -1)
+            self.last_io = dict(encrypt_s=t2 - t1, upload_s=t3 - t2, run_s=t4 - t3, download_s=t5 - t4, decrypt_s=time.time() - t5,
+                                input_bytes=int(cts.nbytes), output_bytes=int(out.nbytes))
         else:
             sess.upload(phases)
             timing = sess.run(timing=True)

@@ -44,7 +44,8 @@ typedef struct {
   int32_t lk, betak;    /* key-switch gadget: levels, base log */
   int32_t ksk_share;    /* >= 0: reuse the key-switch key of that (earlier) tier; -1: own key */
   int32_t unroll;       /* key bits per blind-rotate iteration: 1, or 2 (k = 1, l = 1, n even; key of 3n/2 blocks) */
-  int32_t reserved;
+  int32_t key_lds;      /* 1: the waves of a workgroup share each bootstrap-key tile through LDS (LDS-DMA ring) instead of each pulling its own
+                           copy through L1 -- (k, l, N, unroll) = (2, 1, 1024, 2) only; same results, measured no faster */
   double lwe_sigma;     /* noise std of key-switch-key rows (fraction of the torus) */
   double glwe_sigma;    /* noise std of bootstrap-key rows */
 } dctfhe_tier;
@@ -96,8 +97,9 @@ int dctfhe_ctx_synchronize(dctfhe_ctx* ctx);
  * Randomness: a counter-mode ChaCha20 generator on the GPU keyed by the caller's 32-byte seed (draw it from the OS:
  * os.urandom / getrandom).  The secret-key bits and every noise term come from the seed's own stream; ciphertext and key
  * MASKS come from a second ChaCha20 key that is one block of the first (public: knowing it gives nothing about the seed).
- * A client key is a pure function of (params, seed): persist the 32 bytes to persist it; every rank of a multi-GPU job
- * gets the same keys from the same seed (broadcast the seed, not the keys).
+ * The KEY MATERIAL of a client key is a pure function of (params, seed): persist the 32 bytes to persist it; every rank of a
+ * multi-GPU job gets the same keys from the same seed (broadcast the seed, not the keys).  Encryption randomness is NOT a
+ * function of the seed alone: see dctfhe_encrypt.
  * SECURITY STATUS: parameters follow a fit through published 128-bit sets (dctfhe/params.py), not an estimator run --
  * there is none in this environment; treat the "~128-bit" figure as unverified. */
 int dctfhe_client_key_create(dctfhe_ctx* ctx, const dctfhe_params* params, const uint8_t seed[32], dctfhe_client_key** out);
@@ -127,9 +129,24 @@ int dctfhe_rng_device(dctfhe_ctx* ctx, const uint8_t key[32], uint64_t stream, u
  * draws masks and noise from fresh generator streams (a per-handle call counter). */
 int dctfhe_encrypt(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* phases, size_t count,
                    uint64_t* cts /* count x (D+1) */);
-/* processes sharing one client key (the ranks of a job) must use disjoint counter ranges, e.g. rank << 32 */
-int dctfhe_client_key_set_encrypt_counter(dctfhe_client_key* client, uint64_t next_call);
 int dctfhe_decrypt(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* cts, size_t count, uint64_t* phases);
+/* The same in the COMPACT WIRE FORM: rows of `dim` mask words + the body instead of D + 1 words.  A fresh encryption masks only
+ * params.input_dim words and a circuit output only the ring of its last table tier (dctfhe_session_dims), so the host <-> device
+ * and client <-> server traffic of an image shrinks by D / dim (ResNet-18 48x112^2: 39.5 GB -> 9.9 GB of input per image).
+ * encrypt: input_dim <= dim <= D (words from input_dim on are zero); decrypt: dim <= D (the words a row lacks count as zero).
+ * Both forms of one call hold the same ciphertexts. */
+int dctfhe_encrypt_rows(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* phases, size_t count, int dim,
+                        uint64_t* cts /* count x (dim+1) */);
+int dctfhe_decrypt_rows(dctfhe_ctx* ctx, dctfhe_client_key* client, const uint64_t* cts /* count x (dim+1) */, size_t count, int dim,
+                        uint64_t* phases);
+/* ENCRYPTION RANDOMNESS IS PER HANDLE.  Key material is a pure function of (params, seed) -- persist or broadcast the 32 bytes to
+ * persist or share the key -- but the masks and noise of dctfhe_encrypt come from generator keys derived from the seed AND a 128-bit
+ * nonce that dctfhe_client_key_create draws from the OS (getrandom), at a position given by a per-handle call counter.  Two handles
+ * made from one seed (a re-created key, a second process, the ranks of a job) therefore never draw the same mask or noise.
+ * set_encrypt_counter moves the position inside the handle's own streams (kept for callers that partition them); set_encrypt_nonce
+ * FIXES the nonce -- reproducible experiments and tests only: handles with equal seed, nonce and counter encrypt identically. */
+int dctfhe_client_key_set_encrypt_counter(dctfhe_client_key* client, uint64_t next_call);
+int dctfhe_client_key_set_encrypt_nonce(dctfhe_client_key* client, const uint8_t nonce[16]);
 
 /* R4, server half, one primitive at a time on host buffers (parity tests, integration). */
 int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts, size_t count,
@@ -147,6 +164,19 @@ int dctfhe_round_lut(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int bit_tier, int 
 int dctfhe_conv2d(dctfhe_ctx* ctx, int D, const uint64_t* in, int batch, int Cin, int H, int W,
                   const int8_t* weight /* [Cout][Cin][KH][KW] */, int Cout, int KH, int KW, int stride, int pad,
                   uint64_t* out);
+
+/* K2 one kernel at a time on host buffers (reference backbone.py:102 torch.add, :276 AvgPool2d, and the shift / offset that opens a
+ * rounding chain): rows of `dim` mask words + body whose mask words from `deff` on count as zero -- the storage form of a session's
+ * tensors, here exposed so that the streaming kernels can be checked at mixed effective dimensions outside a circuit.
+ * add: out = a + b, dim_o >= max(deff_a, deff_b).  affine: the first nwords mask words of each inout row become a << shift, the body
+ * (body << shift) + body_add, the words in between are LEFT AS THEY ARE.  sum_pool: KxK window sums, floor semantics (nn.AvgPool2d(K)
+ * drops the border; the 1/K^2 lives in the next table). */
+int dctfhe_add_rows(dctfhe_ctx* ctx, const uint64_t* a, int dim_a, int deff_a, const uint64_t* b, int dim_b, int deff_b, size_t count,
+                    int dim_o, uint64_t* out);
+int dctfhe_affine_rows(dctfhe_ctx* ctx, const uint64_t* a, int dim_a, int deff_a, size_t count, int nwords, int shift, uint64_t body_add,
+                       int dim_o, uint64_t* inout);
+int dctfhe_sum_pool_rows(dctfhe_ctx* ctx, const uint64_t* in /* [batch][C][H][W] rows */, int dim_in, int deff_in, int batch, int C, int H,
+                         int W, int K, int dim_o, uint64_t* out /* [batch][C][H/K][W/K] rows */);
 
 /* K10, client side, plaintext: the DCT front-end of reference data/cvfunctional.py:37-74 + data/cvtransforms.py:56-64,117-208 on
  * uint8 planes (luma [batch][fs*S][fs*S]; two chroma slots [batch][fs*Sc][fs*Sc], Sc = S/2 for the 4:2:0 paths or S):
@@ -172,6 +202,12 @@ int dctfhe_session_create(dctfhe_ctx* ctx, dctfhe_circuit* circ, dctfhe_eval_key
                           int batch, dctfhe_session** out);
 int dctfhe_session_destroy(dctfhe_session* s);
 int dctfhe_session_upload(dctfhe_session* s, const uint64_t* cts_in /* batch x n_in x (D+1); clear: x 1 */);
+/* compact wire form: host rows of dim mask words + body (clear-mode sessions ignore dim).  upload: any 1 <= dim <= D; words a row lacks
+ * count as zero, words beyond the input's effective dimension must BE zero (checked).  download: dim >= the output's effective dimension.
+ * dctfhe_session_dims reports the two effective dimensions (input: what upload keeps; output: the least download accepts). */
+int dctfhe_session_upload_rows(dctfhe_session* s, const uint64_t* cts_in /* batch x n_in x (dim+1) */, int dim);
+int dctfhe_session_download_rows(dctfhe_session* s, uint64_t* cts_out /* batch x n_out x (dim+1) */, int dim);
+int dctfhe_session_dims(dctfhe_session* s, int* in_dim, int* out_dim);
 /* synchronous.  The uploaded input stays resident: run may be called again without a fresh upload (same result). */
 int dctfhe_session_run(dctfhe_session* s, dctfhe_timing* timing /* may be NULL */);
 /* clear-mode sessions (keys == NULL) only: `simulate` with the noise model.  sigma_per_op[i] (fraction of the torus, 0 for

@@ -96,7 +96,12 @@ def test_params_check_accepts_the_catalogues(L):
     (dict(n=0), "n out of range"), (dict(n=41), "n out of range"), (dict(k=2, logN=10), "k*N exceeds D"),
     (dict(l=4), "bad bootstrap gadget"), (dict(l=2, beta=17), "bad bootstrap gadget"), (dict(l=1, beta=29), "bad bootstrap gadget"),
     (dict(unroll=3), "unroll must be 1 or 2"), (dict(unroll=2, l=2), "unroll 2 needs"), (dict(betak=9), "bad key-switch gadget"),
-    (dict(lk=0), "bad key-switch gadget"), (dict(logN=7), "no kernel"), (dict(ksk_share=0), "ksk_share must name an earlier tier")])
+    (dict(lk=0), "bad key-switch gadget"), (dict(logN=7), "k or logN out of range"), (dict(ksk_share=0), "ksk_share must name an earlier tier"),
+    # the gate in front of an untrusted evaluation-key blob needs BOTH bounds on every field
+    (dict(betak=-3), "bad key-switch gadget"), (dict(betak=0), "bad key-switch gadget"), (dict(lk=-1), "bad key-switch gadget"),
+    (dict(lk=64, betak=1), "bad key-switch gadget"), (dict(k=0), "k or logN out of range"), (dict(k=3), "k or logN out of range"),
+    (dict(logN=14), "k or logN out of range"), (dict(lwe_sigma=-1.0), "noise parameter"), (dict(glwe_sigma=float("nan")), "noise parameter"),
+    (dict(key_lds=1), "key_lds"), (dict(key_lds=2, k=2, logN=10, l=1, beta=20, unroll=2), "k*N exceeds D")])
 def test_params_check_rejects(L, over, needle):
     assert L.dctfhe_params_check(C.byref(_params(**over))) != 0
     assert needle in _err(L), _err(L)
@@ -113,6 +118,19 @@ def test_params_check_rejects_shapes(L):
     p.input_dim = 2048
     assert L.dctfhe_params_check(C.byref(p)) != 0 and "input_dim" in _err(L)
     assert L.dctfhe_params_check(None) != 0
+    # caps: sizes computed from the parameters (key allocations, the blob size an import compares with) stay far inside size_t
+    p = _params()
+    p.D = 1 << 17
+    assert L.dctfhe_params_check(C.byref(p)) != 0 and "65536" in _err(L)
+    p = _params()
+    p.n_max = 1 << 20
+    assert L.dctfhe_params_check(C.byref(p)) != 0 and "n_max" in _err(L)
+    p = _params()
+    p.n_max = 0
+    assert L.dctfhe_params_check(C.byref(p)) != 0 and "n_max" in _err(L)
+    p = _params()
+    p.input_sigma = -0.5
+    assert L.dctfhe_params_check(C.byref(p)) != 0 and "input_sigma" in _err(L)
 
 
 # ------------------------------------------------------------------------------------------ circuit blobs

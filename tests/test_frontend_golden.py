@@ -98,3 +98,60 @@ def test_filter8_eval_transform_shapes():
     for ch in (48, 64):
         x = frontend.dct_eval_transform(filter_size=8, image_size_dct=14, channels=ch)(img)
         assert x.shape == (ch, 14, 14) and x.dtype == np.float32 and np.isfinite(x).all()
+
+
+def test_subset_patterns_square_triangle_learned():
+    """every SubsetDCT pattern of the reference (cvtransforms.py:117-128) from the captured tables; the two spelled-out tables agree with
+    the captured ones; NormalizeDCT keeps indexing the statistics with the DEFAULT table whatever the pattern (datamgr.py:209-216)"""
+    from dctfhe import frontend
+    T = frontend.subset_tables()
+    assert set(T) == {"filter4", "default", "square", "learned", "triangle"}
+    for ch, v in frontend.SUBSET_DEFAULT.items():
+        assert tuple(map(list, v)) == T["default"][ch]
+    for ch, v in frontend.SUBSET_FILTER4.items():
+        assert tuple(map(list, v)) == T["filter4"][ch]
+    for pattern, ch, sizes in [("square", 24, (16, 4, 4)), ("triangle", 24, (12, 6, 6)), ("learned", 24, (14, 5, 5)), ("triangle", 48, (28, 10, 10)),
+                               ("square", 64, (44, 10, 10)), ("default", 32, (22, 5, 5))]:
+        y, cb, cr = frontend.subset_indices(ch, pattern, 8)
+        assert (len(y), len(cb), len(cr)) == sizes and len(y) + len(cb) + len(cr) == ch
+        assert all(0 <= i < 64 for i in y + cb + cr) and len(set(y)) == len(y)
+    assert frontend.subset_indices(24, "square", 4) == frontend.subset_indices(24, "default", 4)       # filter 4 ignores the pattern
+    # whole transform with a non-default pattern: selection by the pattern's table, statistics by the default one
+    rng = np.random.default_rng(5)
+    planes = [rng.normal(0, 30, (64, 6, 6)).astype(np.float32) for _ in range(3)]
+    out = frontend.subset_aggregate_normalize(*planes, channels=24, pattern="triangle", filter_size=8)
+    y, cb, cr = frontend.subset_indices(24, "triangle", 8)
+    mean, std = frontend.load_stats()
+    idx = frontend.normalize_indices(24)
+    want = (np.concatenate([planes[0][y], planes[1][cb], planes[2][cr]]) - mean[idx].astype(np.float32)[:, None, None]) / std[idx].astype(np.float32)[:, None, None]
+    assert out.shape == (24, 6, 6) and np.array_equal(out, want)
+    with pytest.raises(ValueError, match="no 'learned' coefficient table"):
+        frontend.subset_indices(48, "learned", 8)
+    with pytest.raises(ValueError, match="dct_pattern"):
+        frontend.subset_indices(24, "zigzag", 8)
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=4, channels=24, dct_pattern="square")
+    assert tf(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)).shape == (24, 4, 4)
+
+
+def test_jpeg_integer_dct_restatement():
+    """libjpeg's integer forward DCT + quality-100 quantiser (frontend.jpeg_quantised_dct; PARITY UNPINNED -- TurboJPEG / jpeg2dct absent):
+    integers only; within libjpeg's documented accuracy of the exact DCT (the scaled-by-8 result is good to about one unit, i.e. 1/8 here,
+    before the quantiser rounds); exact on constant blocks; linear in the DC term."""
+    from dctfhe import frontend
+    rng = np.random.default_rng(9)
+    pl = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    q = frontend.jpeg_quantised_dct(pl)
+    assert q.dtype == np.int64 and q.shape == (6, 8, 64)
+    exact = frontend.matrix2dct(pl, 8)
+    assert np.abs(q - exact).max() <= 0.5 + 0.15                      # rounding + the fixed-point transform's own error
+    assert (q == frontend._round_half_away(exact)).mean() > 0.85      # ... so most coefficients are the rounded exact ones, not all
+    flat = np.full((8, 8), 200, np.uint8)
+    qf = frontend.jpeg_quantised_dct(flat)[0, 0]
+    assert qf[0] == (200 - 128) * 8 and not qf[1:].any()              # DC = 8 * mean for the orthonormal 8x8 DCT, AC = 0
+    # DC-term ties: a block mean with fraction 1/16 puts the exact DC on x.5; the integer path rounds half away from zero, both signs
+    for v, want in [(129, 8), (127, -8)]:
+        blk = np.full((8, 8), 128, np.uint8)
+        blk[0, :4] = v                                                # sum of (p - 128) = +-4 -> DC = +-0.5 -> +-1
+        assert frontend.jpeg_quantised_dct(blk)[0, 0, 0] == (1 if v > 128 else -1)
+    a, b, c = frontend.transform_dct_jpeg(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8))
+    assert a.shape == (4, 4, 64) and b.shape == c.shape == (2, 2, 64) and np.array_equal(a, np.rint(a))

@@ -47,30 +47,42 @@ def test_device_front_end_equals_numpy_front_end(gpu_ctx, channels):
 
 
 def test_jpeg_domain_planes_and_errors(gpu_ctx):
-    """round_coeffs: integer coefficient planes (the filter-8 path's quantised JPEG coefficients), up-sampled and rounded to even"""
+    """round_coeffs (block size 8): libjpeg's integer DCT + quantiser on the device -- integer coefficient planes EQUAL to the host
+    restatement (frontend.jpeg_quantised_dct), ties included (round 2 ran a float DCT here and the test had to tolerate +-1 on ties);
+    chroma grids up-sampled and rounded to even like the reference's int16 planes"""
     from dctfhe import frontend
     from dctfhe._lib import DctfheError
     rng = np.random.default_rng(3)
     y = rng.integers(0, 256, (2, 32, 32), dtype=np.uint8)
     c = rng.integers(0, 256, (2, 16, 16), dtype=np.uint8)
+    y[1, :8, :8] = 128
+    y[1, 0, :4] = 129                                                    # a DC term exactly on a rounding tie (+0.5)
+    y[1, 8:16, :8] = 128
+    y[1, 8, :4] = 127                                                    # ... and on -0.5
     sy, scb, scr = frontend.subset_indices(48, "default", 8)
     out = gpu_ctx.dct_frontend(y, c, c, 8, (sy, scb, scr), np.zeros(48), np.ones(48), round_coeffs=True)
     assert out.shape == (2, 48, 4, 4) and np.array_equal(out, np.rint(out))
-
-    def same_up_to_ties(got, unrounded, rounded):
-        """equal wherever the unrounded value is not (numerically) on a rounding tie -- DC terms are multiples of 1/8, so
-        exact .5 ties occur and two summation orders may fall on either side (libjpeg's integer DCT differs there too)"""
-        tie = np.abs(np.abs(unrounded - np.floor(unrounded)) - 0.5) < 1e-6
-        assert np.array_equal(got[~tie], rounded[~tie].astype(np.float32)) and np.abs(got - rounded).max() <= 1 and tie.mean() < 0.05
-
-    raw_y = frontend.matrix2dct(y[0], 8).transpose(2, 0, 1)[sy]
-    same_up_to_ties(out[0, :len(sy)], raw_y, frontend._round_half_away(raw_y))
-    # chroma: compare on blocks where no coefficient of the 2x2 source grid sits on a tie
-    cq = frontend._round_half_away(frontend.matrix2dct(c[0], 8))
-    raw_c = frontend._bilinear(cq, 4, 4).transpose(2, 0, 1)[scb]
-    got_c = out[0, len(sy):len(sy) + len(scb)]
-    assert np.abs(got_c - np.rint(raw_c)).max() <= 1 and (got_c == np.rint(raw_c).astype(np.float32)).mean() > 0.95
+    for b in range(2):
+        want_y = frontend.jpeg_quantised_dct(y[b]).transpose(2, 0, 1)[sy]
+        assert np.array_equal(out[b, :len(sy)], want_y.astype(np.float32))
+        cq = frontend.jpeg_quantised_dct(c[b]).astype(np.float64)
+        want_c = np.rint(frontend._bilinear(cq, 4, 4)).transpose(2, 0, 1)[scb]
+        assert np.array_equal(out[b, len(sy):len(sy) + len(scb)], want_c.astype(np.float32))
+    assert out[1, 0, 0, 0] == 1 and out[1, 0, 1, 0] == -1               # the two ties: half away from zero, as libjpeg's quantiser
     with pytest.raises(DctfheError, match="index out of range"):
         gpu_ctx.dct_frontend(y, c, c, 8, ([64], [], []), np.zeros(1), np.ones(1))
     with pytest.raises(DctfheError, match="bad geometry"):
         gpu_ctx.dct_frontend(y[:, :24, :24], c, c, 8, (sy, scb, scr), np.zeros(48), np.ones(48))
+
+
+def test_device_front_end_filter8_equals_numpy_front_end(gpu_ctx):
+    """config #5's transform (8x8 JPEG-domain DCT, 48 channels) with DCT / quantiser / subset / up-sampling / normalisation on the GPU:
+    the same float32 tensor as the numpy path (every stage before the final (x - mean) / std is integer)"""
+    from dctfhe import frontend, synthetic
+    imgs = synthetic.synthetic_images(3, 43, size=48)
+    got = frontend.device_dct_batch(gpu_ctx, imgs, filter_size=8, image_size_dct=8, channels=48)
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=8, channels=48)
+    want = np.stack([tf(im) for im in imgs])
+    assert got.shape == want.shape == (3, 48, 8, 8) and got.dtype == np.float32
+    # (the integer planes are compared bit for bit in the test above; here one f32 (x - mean) / std on top: an ulp at most)
+    assert np.abs(got - want).max() <= 2e-7 * max(1.0, np.abs(want).max())

@@ -43,9 +43,33 @@ def test_keys_are_a_function_of_the_seed(gpu_ctx):
         ph = np.arange(4, dtype=np.uint64) << np.uint64(58)
         c1, c2 = a.encrypt(ph), a.encrypt(ph)
         assert not np.any(c1[:, :8] == c2[:, :8]) and np.array_equal((a.decrypt(c1) + np.uint64(1 << 56)) >> np.uint64(57), (a.decrypt(c2) + np.uint64(1 << 56)) >> np.uint64(57))
-        # ... and neither do two ranks that share the key but took their own counter ranges
-        b.set_encrypt_counter(1 << 32)
-        assert not np.any(b.encrypt(ph)[:, :8] == c1[:, :8])
+        # ... and neither do two HANDLES made from one seed (a re-created key, another process, the ranks of a job), by default and
+        # at the same call counter: the encryption streams hang on a per-handle nonce from the OS, not on the seed alone (ADVICE r2:
+        # before, b.encrypt re-drew a's masks and noise, and ct_a - ct_b = (0, m_a - m_b) gave away plaintext differences)
+        b.set_encrypt_counter(0)
+        a2 = ClientKey(gpu_ctx, cp, 5)
+        cb, ca2 = b.encrypt(ph), a2.encrypt(ph)
+        assert not np.any(cb[:, :8] == c1[:, :8]) and not np.any(ca2[:, :8] == c1[:, :8]) and not np.any(ca2[:, :8] == cb[:, :8])
+        assert not np.any(cb[:, -1] == c1[:, -1]) and not np.any(ca2[:, -1] == c1[:, -1])            # bodies: other masks AND other noise
+        rnd = lambda x: (x + np.uint64(1 << 56)) >> np.uint64(57)
+        assert np.array_equal(rnd(a.decrypt(cb)), rnd(a.decrypt(c1))) and np.array_equal(rnd(a.decrypt(ca2)), rnd(ph))       # same key all the same
+        # only a caller who FIXES the nonce (reproducible experiments) gets equal ciphertexts from equal (seed, nonce, counter)
+        for h in (a2, b):
+            h.set_encrypt_nonce(bytes(range(16)))
+            h.set_encrypt_counter(7)
+        assert np.array_equal(a2.encrypt(ph), b.encrypt(ph))
+        a2.set_encrypt_nonce(bytes(range(1, 17)))
+        a2.set_encrypt_counter(8)
+        assert not np.any(a2.encrypt(ph)[:, :8] == b.encrypt(ph)[:, :8])
+        a2.close()
+        # the compact wire form holds the same ciphertexts as the full-width form of the same call
+        D, dim = a.D, a.input_dim
+        for h in (a, b):
+            h.set_encrypt_nonce(bytes(range(16)))
+            h.set_encrypt_counter(20)
+        full, compact = a.encrypt(ph), b.encrypt(ph, dim)
+        assert compact.shape == (4, dim + 1) and np.array_equal(full[:, :dim], compact[:, :dim]) and np.array_equal(full[:, D], compact[:, dim])
+        assert not full[:, dim:D].any() and np.array_equal(a.decrypt(full), a.decrypt(compact, dim))
         ea.close(); eb.close()
     finally:
         a.close(); b.close(); c.close()
@@ -69,6 +93,13 @@ def test_server_evaluates_with_imported_evaluation_keys():
         cts_out = server.evaluate_encrypted(cts_in, batch=3)
         got = client.decode_output(client._keys.client.decrypt(cts_out).reshape(3, -1))
         assert np.array_equal(got, _oracle_out(client, q))
+        # the same exchange in the compact wire form: input rows of input_dim + 1 words, output rows of the last tier's ring + 1
+        dim = client._keys.client.input_dim
+        cts_c = client._keys.client.encrypt(client.encode_input(q).reshape(-1), dim)
+        out_c = server.evaluate_encrypted(cts_c, batch=3, dim=dim)
+        out_dim = out_c.shape[1] - 1
+        assert out_dim == server._session("execute", 3).dims()[1] <= client._keys.D and cts_c.shape[1] == dim + 1
+        assert np.array_equal(client.decode_output(client._keys.client.decrypt(out_c, out_dim).reshape(3, -1)), _oracle_out(client, q))
         # a corrupted / truncated blob is refused, not half-loaded
         from dctfhe._lib import DctfheError
         with pytest.raises(DctfheError, match="blob"):

@@ -124,6 +124,66 @@ def test_pbs_two_bit_rotation_k2(gpu_ctx, oracle):
         k.close()
 
 
+def test_pbs_two_bit_rotation_k2_key_tiles_through_lds(gpu_ctx, oracle):
+    """tier.key_lds = 1: the eight ciphertexts of a workgroup share every key tile through an LDS ring filled by LDS-DMA (pbs_core.h,
+    KLDS) -- against the same definition, and ciphertext for ciphertext the same decrypted values as the free-running kernel.
+    20 ciphertexts: two full workgroups and a padded one."""
+    from dctfhe.engine import Keys, make_params
+    D, w, N = 2048, 3, 1024
+    base = dict(n=40, k=2, logN=10, l=1, beta=20, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -52, unroll=2)
+    k = Keys(gpu_ctx, make_params(D, 40, [dict(base, key_lds=1), dict(base, ksk_share=0)], 2.0 ** -50), seed=23)
+    try:
+        S, s = k.export_secret()
+        msgs = np.arange(20, dtype=np.uint64) % (1 << w)
+        small = oracle.lwe_encrypt(s[:40].copy(), 40, msgs << np.uint64(63 - w), 2.0 ** -30, seed=15)
+        f = (np.arange(1 << w, dtype=np.uint64) * 5 + 2) % (1 << w)
+        table = f.astype(np.int64) << (63 - w - 2)
+        dev = k.pbs(0, small, table, w)
+        free = k.pbs(1, small, table, w)
+        ref = oracle.pbs_mb2(small[:8], k.export_bsk(0), 2, N, 1, 20, table, w, None, D)
+        dec = lambda ph: ((ph + (np.uint64(1) << np.uint64(63 - w - 3))) >> np.uint64(63 - w - 2)) & np.uint64((1 << (w + 2)) - 1)
+        ph_dev, ph_free, ph_ref = oracle.lwe_phase(S, D, dev), oracle.lwe_phase(S, D, free), oracle.lwe_phase(S, D, ref)
+        assert np.array_equal(dec(ph_dev), f[msgs]) and np.array_equal(dec(ph_free), f[msgs]) and np.array_equal(dec(ph_ref), f[msgs[:8]])
+        want = table.astype(np.uint64)[msgs]
+        err_dev, err_ref = np.abs(_centered(ph_dev - want)), np.abs(_centered(ph_ref - want[:8]))
+        assert err_dev.max() < max(4 * err_ref.max(), 2.0 ** -30), (err_dev.max(), err_ref.max())
+        assert not dev[:, 2 * N: D].any()
+    finally:
+        k.close()
+
+
+@pytest.mark.parametrize("logN,w,beta", [(13, 6, 22), (12, 5, 22)])
+def test_pbs_two_bit_rotation_shipped_big_rings(gpu_ctx, oracle, logN, w, beta):
+    """The two instantiations that carry half of an image -- pbs_kernel<13,1,1,8,1,1> (tier T6a: one ciphertext per 512-thread
+    workgroup, twist bases read from global memory, 32-part L2 warm-up) and <12,1,1,8,2,1> (T5a: two ciphertexts per workgroup) --
+    against the exact-arithmetic definition of the two-bit rotation (oracle ref_pbs_mb2_batch), at the shipped ring, gadget and
+    table width with a short key (n = 40: the exact product is ~N^2 per external product)."""
+    from dctfhe import params as P
+    from dctfhe.engine import Keys, make_params
+    D, N, n = 8192, 1 << logN, 40
+    tier = dict(n=n, k=1, logN=logN, l=1, beta=beta, lk=4, betak=4, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -62, unroll=2)
+    k = Keys(gpu_ctx, make_params(D, n, [tier], 2.0 ** -62), seed=29)
+    try:
+        S, s = k.export_secret()
+        msgs = np.array([0, 5, 13, 21, 31, 42, 50, 63], dtype=np.uint64) % (1 << w)
+        small = oracle.lwe_encrypt(s[:n].copy(), n, msgs << np.uint64(63 - w), 2.0 ** -30, seed=16)
+        f = (np.arange(1 << w, dtype=np.uint64) * 7 + 3) % 16                      # 4-bit outputs, as the shipped tables have
+        table = f.astype(np.int64) << 57
+        dev = k.pbs(0, small, table, w)
+        ref = oracle.pbs_mb2(small, k.export_bsk(0), 1, N, 1, beta, table, w, None, D)
+        ph_dev, ph_ref = oracle.lwe_phase(S, D, dev), oracle.lwe_phase(S, D, ref)
+        dec = lambda ph: ((ph + (np.uint64(1) << np.uint64(56))) >> np.uint64(57)) & np.uint64(63)
+        assert np.array_equal(dec(ph_dev), f[msgs]) and np.array_equal(dec(ph_ref), f[msgs])
+        want = table.astype(np.uint64)[msgs]
+        err_dev, err_ref = np.abs(_centered(ph_dev - want)), np.abs(_centered(ph_ref - want))
+        # the definition is exact arithmetic; the device's one-level f64 transform carries the N^2 B^2 error the compiler prices
+        model = P.var_pbs_out(P.TierSpec("t", n=n, k=1, logN=logN, l=1, beta=beta, lk=4, betak=4, unroll=2, lwe_sigma=2.0 ** -24, glwe_sigma=2.0 ** -62)) ** 0.5
+        assert err_dev.max() < max(4 * err_ref.max(), 5 * model), (err_dev.max(), err_ref.max(), model)
+        assert not dev[:, N: D].any()
+    finally:
+        k.close()
+
+
 @pytest.mark.parametrize("l,beta", [(1, 20), (3, 12)])
 def test_pbs_two_bit_rotation(gpu_ctx, oracle, l, beta):
     """tier.unroll == 2 (two key bits per blind-rotate iteration, csrc/pbs_core.h): every message decodes to f(m), the

@@ -5,6 +5,7 @@ SURVEY.md Appendix E: inert stand-ins are registered for the *absent* third-part
 (cv2, turbojpeg, jpeg2dct, brevitas) so that module-level imports succeed; any reference function
 that would really call one of them is NOT used as an oracle.  What is captured:
   - data.train_upscaled_static_mean/std          (192-entry data constants, data/__init__.py:289,329)
+  - cvtransforms.subset_channel_index*           (index tables of the five SubsetDCT patterns, data constants)
   - cvfunctional.matrix2dct on seeded planes     (cvfunctional.py:37-57)
   - cvtransforms.SubsetDCT/Aggregate/NormalizeDCT on seeded tensors (cvtransforms.py:117-208)
   - the float twin models.backbone.ResNet20/ResNet18: conv output shapes, parameter counts
@@ -40,6 +41,12 @@ def main():
     mean = np.array(data.train_upscaled_static_mean, np.float64)
     std = np.array(data.train_upscaled_static_std, np.float64)
     np.savez(os.path.join(ROOT, "dct-cryptonets_amd", "dctfhe", "data", "dct_stats.npz"), mean=mean, std=std)
+    # the kept-coefficient index tables of SubsetDCT / NormalizeDCT for every pattern (data constants, cvtransforms.py:1600-1860)
+    import json
+    tables = {"filter4": Tr.subset_channel_index_filtersize_4, "default": Tr.subset_channel_index, "square": Tr.subset_channel_index_square,
+              "learned": Tr.subset_channel_index_learned, "triangle": Tr.subset_channel_index_triangle}
+    with open(os.path.join(ROOT, "dct-cryptonets_amd", "dctfhe", "data", "subset_tables.json"), "w") as f:
+        json.dump({name: {str(ch): [list(map(int, part)) for part in v] for ch, v in d.items()} for name, d in tables.items()}, f, separators=(",", ":"))
 
     g = {"stats_mean": mean, "stats_std": std}
     rng = np.random.default_rng(0)
