@@ -14,7 +14,8 @@ Usage:  python bench.py --gpus N --steps K --warmup W [--batch-per-gpu B] [--bud
     under torch.distributed.run it is one of the ranks.
   * One encrypted image takes seconds, so K and W are CAPPED by a wall-clock budget (--budget-s, default 450 s from
     process start, env DCTFHE_BENCH_BUDGET_S): after the first pass the loop keeps as many of the requested passes
-    as fit; the JSON reports the steps / warm-up passes actually run (and `requested`).
+    as fit; the JSON reports the steps / warm-up passes actually run (and `requested`).  When not even a second pass
+    fits (multi-image configs whose pass takes minutes), the first pass -- bracketed like a step -- is the timed step.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -77,7 +78,7 @@ def measured_hbm_traffic(kernel_tag, cts_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (tools/rocprof_db_summary.py; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected inside this run).  Scaled by ciphertexts per
     launch; None when the summary has no entry for this kernel."""
-    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    for name in ("r03_pmc_hbm.json", "r02_pmc_hbm.json", "r01_pmc_hbm.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -227,7 +228,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from dctfhe.sharding import gather_in_image_order, shard_indices
+    from dctfhe.sharding import agree_min, all_true, barrier, broadcast_seed, gather_in_image_order, max_over_ranks, shard_indices
 
     if args.launch_check:
         dist.init_process_group("gloo")
@@ -282,45 +283,44 @@ def main():
     t0 = time.time()
     # one 256-bit key seed for the whole job: rank 0 draws it from the OS and broadcasts it; every rank regenerates the same
     # client + evaluation keys from it on its own GPU (no key traffic) and encrypts from its own counter range
-    seed_t = torch.tensor(list(os.urandom(32)), dtype=torch.uint8)
-    if world > 1:
-        seed_t = seed_t.to(cdev)
-        dist.broadcast(seed_t, 0)
-        seed_t = seed_t.cpu()
-    qm.fhe_circuit.keygen(seed=bytes(seed_t.tolist()))
-    qm._keys.client.set_encrypt_counter(rank << 32)
+    qm.fhe_circuit.keygen(seed=broadcast_seed(os.urandom(32), world, cdev))
+    # (every rank's client handle draws its own 128-bit encryption nonce from the OS: ranks sharing the seed never share masks or noise)
     keygen_s = time.time() - t0
     stats = qm.statistics()
     # seeded classifier with logits centred on the calibration features (clear circuit): labels differ between images
     from dctfhe.synthetic import centre_classifier
     centre_classifier(model, qm.forward(calib[:32], fhe="disable"))
 
-    # this rank's shard of the global synthetic batch: image i -> rank i % world
+    # this rank's shard of the global synthetic batch: image i -> rank i % world.  Client-side stages are timed one by one for the
+    # reference-style end-to-end figure (homomorphic_eval.py:350-361 times transform + quantise + encrypt + run + decrypt + classifier)
+    t_fe = time.time()
     x_all = make_batch(B * world, 42)
+    frontend_s = (time.time() - t_fe) / world          # front-end of this rank's share (the batch maker transforms every image)
     x = x_all[shard_indices(B * world, rank, world)]
+    t_q = time.time()
     q = qm.quantize_input(x)
     phases = qm.encode_input(q)
+    quantize_s = time.time() - t_q
     sess = qm._session("execute", B)
-    cts = qm._keys.encrypt(phases.reshape(-1))
+    in_dim, out_dim = sess.dims()         # compact wire form: rows of input_dim + 1 / last ring + 1 words, not D + 1
+    t_enc = time.time()
+    cts = qm._keys.encrypt(phases.reshape(-1), in_dim)
+    encrypt_s = time.time() - t_enc
     t_up = time.time()
-    sess.upload(cts)                      # inputs resident in HBM before the timed region
+    sess.upload(cts, in_dim)              # inputs resident in HBM before the timed region
     upload_s = time.time() - t_up         # host -> device copy of the encrypted batch (reported, never part of `value`)
     input_bytes = cts.nbytes
     del cts
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        barrier(world)
         torch.cuda.synchronize()
         qm._ctx.synchronize()
 
     def agree(warm, steps):
         """every rank runs the same number of passes: the minimum over ranks"""
-        if world == 1:
-            return warm, steps
-        tt = torch.tensor([warm, steps], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-        return int(tt[0].item()), int(tt[1].item())
+        w, st = agree_min([warm, steps], world, cdev)
+        return w, st
 
     # ---- wall-clock budget -------------------------------------------------------------------------------------------------
     reserve_s = 25.0                     # decrypt + clear circuit + JSON + teardown
@@ -335,53 +335,74 @@ def main():
         interrupted["flag"] = True
     signal.signal(signal.SIGTERM, on_term)
 
-    warm_total, steps_total = args.warmup, args.steps
-    warm_done = 0
-    state["phase"] = "warm-up"
-    while warm_done < warm_total and not interrupted["flag"]:
-        t0 = time.time()
-        sess.run()
-        dt = time.time() - t0
-        warm_done += 1
-        state.update(passes=warm_done, last_s=dt)
-        if warm_done == 1:               # plan the rest from the first pass
-            warm_total, steps_total = agree(*plan_passes(args.warmup, args.steps, 1, 0, dt, remaining()))
+    # ---- passes.  The FIRST pass is bracketed and timed like a step (barrier + synchronize on both sides).  If what is left of the
+    # budget after it does not hold another pass, it IS the timed step (reported: first_pass_counted) -- a multi-image config whose one
+    # pass takes minutes (ResNet-18 3x32^2 with 8 images per GPU: ~5 min) then still ends inside the driver's wall instead of running a
+    # warm-up pass and a timed pass back to back.  Otherwise it is the first warm-up pass and the plan for the rest is made from it.
+    state["phase"] = "first pass"
+    sync()
+    t_first = time.time()
+    first_timing = sess.run(timing=True)
+    sync()
+    first_s = max_over_ranks(time.time() - t_first, world, cdev)
+    state.update(passes=1, last_s=first_s)
+    can_continue = all_true(remaining() >= 1.15 * first_s and not interrupted["flag"], world, cdev)
+    timings = []
+    warm_done, steps_done = 0, 0
+    first_pass_counted = not can_continue or (args.warmup == 0 and args.steps <= 1)
+    if first_pass_counted:
+        timings.append(first_timing)
+        steps_done, elapsed = 1, first_s
+    else:
+        if args.warmup == 0:
+            # no warm-up asked for: the first pass is step 1 of the timed region; the remaining steps follow and are timed together
+            timings.append(first_timing)
+            steps_done = 1
+            _, steps_total = agree(*plan_passes(0, args.steps, 0, 1, first_s, remaining()))
+            warm_total = 0
+        else:
+            warm_done = 1
+            warm_total, steps_total = agree(*plan_passes(args.warmup, args.steps, 1, 0, first_s, remaining()))
+        state["phase"] = "warm-up"
+        while warm_done < warm_total and not interrupted["flag"]:
+            t0 = time.time()
+            sess.run()
+            warm_done += 1
+            state.update(passes=warm_done, last_s=time.time() - t0)
     if cpu_thread is not None:
         state["phase"] = "waiting for the CPU baseline"
         cpu_thread.join()
-    state["phase"] = "timed steps"
-    sync()
-    t0 = time.time()
-    timings = []
-    steps_done = 0
-    while steps_done < steps_total and not interrupted["flag"]:
-        ts = time.time()
-        timings.append(sess.run(timing=True))
-        steps_done += 1
-        state.update(passes=warm_done + steps_done, last_s=time.time() - ts)
-        if warm_done == 0 and steps_done == 1:     # --warmup 0: plan from the first timed step
-            _, steps_total = agree(*plan_passes(0, args.steps, 0, 1, time.time() - ts, remaining()))
-    sync()
-    elapsed = time.time() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if not first_pass_counted:
+        state["phase"] = "timed steps"
+        sync()
+        t0 = time.time()
+        while steps_done < steps_total and not interrupted["flag"]:
+            ts = time.time()
+            timings.append(sess.run(timing=True))
+            steps_done += 1
+            state.update(passes=warm_done + steps_done, last_s=time.time() - ts)
+        sync()
+        elapsed = max_over_ranks(time.time() - t0, world, cdev) + (first_s if args.warmup == 0 else 0.0)
     state["phase"] = "decrypt + check"
 
     # decrypt this shard, classify in the clear (reference utils.py:22), gather logits over RCCL
-    out = sess.download().reshape(-1, qm._keys.D + 1)
-    feats_q = qm.decode_output(qm._keys.decrypt(out).reshape(B, -1))
+    t_dl = time.time()
+    out = sess.download(out_dim).reshape(-1, out_dim + 1)
+    download_s = time.time() - t_dl
+    output_bytes = out.nbytes
+    t_dec = time.time()
+    feats_q = qm.decode_output(qm._keys.decrypt(out, out_dim).reshape(B, -1))
+    decrypt_s = time.time() - t_dec
+    t_cls = time.time()
+    feats = torch.from_numpy(qm.dequantize_output(feats_q)).float()
+    logits = feats @ torch.from_numpy(model.classifier_w).float().T + torch.from_numpy(model.classifier_b).float()
+    classifier_s = time.time() - t_cls
     clear_q = qm.forward_quantized(q, "disable")
     exact = bool(np.array_equal(feats_q, clear_q))
     diff = np.abs(feats_q.astype(np.int64) - clear_q.astype(np.int64))
-    feats = torch.from_numpy(qm.dequantize_output(feats_q)).float()
-    logits = feats @ torch.from_numpy(model.classifier_w).float().T + torch.from_numpy(model.classifier_b).float()
     if world > 1:
         all_logits = gather_in_image_order(logits.to(cdev), world).cpu()      # one RCCL all_gather, global image order
-        flags = torch.tensor([1.0 if exact else 0.0], device=cdev)
-        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-        exact = bool(flags.item() > 0.5)
+        exact = all_true(exact, world, cdev)
     else:
         all_logits = logits
 
@@ -424,10 +445,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 torus + f64 FFT",
+            "dtype": "u64 torus + f64 FFT (one-level tiers keep 32-bit accumulators)",
             "data": "synthetic",
             "requested": {"steps": args.steps, "warmup": args.warmup, "budget_s": args.budget_s,
-                          "capped_by_budget": bool(steps < args.steps or warm_done < args.warmup), "interrupted": interrupted["flag"]},
+                          "capped_by_budget": bool(steps < args.steps or warm_done < args.warmup), "interrupted": interrupted["flag"],
+                          "first_pass_counted": bool(first_pass_counted), "first_pass_s": first_s},
             "s_per_image": elapsed / (B * steps),
             "config": {"workload": f"{workload}, {B} encrypted image(s) per GPU and step, " +
                                    ("exact-evaluation tiers" if args.tier_policy == "exact" else "p_error=0.01 tiers (stochastic outputs, speed only)") +
@@ -437,19 +459,23 @@ def main():
                        "step_s_min_max": [min(step_s), max(step_s)] if step_s else None,
                        "pbs_per_image": int(sum(stats.pbs_count)), "bit_steps_per_image": int(stats.bit_steps),
                        "table_lookups_per_image": int(stats.lut_sites), "conv_macs_per_image": int(stats.conv_macs),
-                       "max_bit_width": int(stats.max_bit_width), "compile_s": compile_s, "keygen_s": keygen_s, "key_seed": "32 bytes of os.urandom on rank 0, broadcast",
-                       "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes),
+                       "max_bit_width": int(stats.max_bit_width), "compile_s": compile_s, "keygen_s": keygen_s,
+                       "key_seed": "32 bytes of os.urandom on rank 0, broadcast; each rank's handle draws its own 128-bit encryption nonce",
+                       "input_upload_s": upload_s, "input_bytes_per_gpu": int(input_bytes), "output_bytes_per_gpu": int(output_bytes),
+                       "wire_format": f"compact rows: {in_dim} + 1 words per input ciphertext, {out_dim} + 1 per output (D = {ps.D})",
                        "images_per_s_pcie_inclusive": images / (elapsed + upload_s * steps),
                        "bit_exact_vs_integer_circuit": exact, "tier_policy": args.tier_policy, "rounding_method": args.rounding_method,
                        "outputs_equal_frac": float((diff == 0).mean()), "outputs_max_abs_diff": int(diff.max()),
                        "expected_boundary_flips_per_image": float(getattr(qm.compiled, "expected_boundary_flips_per_image", 0.0)),
                        "predicted_labels": all_logits.argmax(dim=1).tolist(),
                        "expected_table_failures_per_image": qm.compiled.expected_failures_per_image},
-            "roofline": {"bound": "hbm", "kernel": f"pbs_kernel<logN={td.logN},k={td.k},l={td.l}> (tier {td.name})",
+            "roofline": {"bound": "hbm", "binding": "roofline_fp64", "binding_frac": achieved_tf / FP64_SPEC_TFLOPS,
+                         "kernel": f"pbs_kernel<logN={td.logN},k={td.k},l={td.l}> (tier {td.name})",
                          "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": measured_hbm_traffic(f"pbs_kernel<{td.logN},{td.k},{td.l},", cts_per_launch), "avg_launch_ms": avg_launch_s * 1e3, "cts_per_launch": cts_per_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the blind rotate is f64-VALU/LDS bound (SURVEY 8d); see roofline_fp64 for the bounding roof"},
+                         "note": "HBM is NOT the roof this kernel sits under: the blind rotate is f64-VALU / LDS bound (SURVEY 8d). The binding roof is "
+                                 "roofline_fp64 (same launch, same measured duration); `binding_frac` repeats its fraction here"},
             "roofline_fp64": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_SPEC_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tf / FP64_SPEC_TFLOPS, "peak_live_fma_probe": fp64_live,
                               "frac_of_live_probe": achieved_tf / fp64_live, "flops_per_bootstrap": flops_per_pbs},
@@ -461,6 +487,12 @@ def main():
                             "flops_f64_per_image": stats.flops_f64,
                             "hbm_frac_whole_pipeline": (stats.bytes_algorithmic + stats.key_bytes_per_pass / B) * B * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                             "fp64_frac_whole_pipeline": stats.flops_f64 * B * steps / elapsed / 1e12 / FP64_SPEC_TFLOPS},
+            # reference-style end to end (homomorphic_eval.py:350-361: DataLoader transform + forward(quantise, encrypt, run, decrypt,
+            # dequantise) + clear classifier, `elapsed / test_subset`), this rank's shard, every stage measured in this run
+            "end_to_end": {"frontend_s": frontend_s, "quantize_s": quantize_s, "encrypt_s": encrypt_s, "upload_s": upload_s,
+                           "run_s_per_step": elapsed / steps, "download_s": download_s, "decrypt_s": decrypt_s, "classifier_s": classifier_s,
+                           "e2e_s_per_image": (frontend_s + quantize_s + encrypt_s + upload_s + elapsed / steps + download_s + decrypt_s + classifier_s) / B,
+                           "note": "client stages on the host CPU (numpy front-end) and the GPU (encrypt / decrypt kernels), PCIe both ways included"},
             "consistency": {"wall_since_start_s": wall_now, "timed_s": elapsed, "fits_in_driver_run": bool(elapsed <= wall_now)},
         }
         vi = VALU_PER_ITERATION.get((td.logN, td.k, td.l, unroll))

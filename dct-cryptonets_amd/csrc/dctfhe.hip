@@ -656,6 +656,8 @@ extern "C" int dctfhe_keygen(dctfhe_ctx* ctx, const dctfhe_params* params, const
 extern "C" int dctfhe_eval_keys_destroy(dctfhe_eval_keys* E) { delete E; return 0; }
 
 // ---- evaluation-key persistence: header + params, then per tier its own key-switch key (u64) and its Fourier bootstrap key
+// version 2: the Fourier bootstrap keys carry 2^-64 / M (accumulator updates in units of the whole torus, fft_core.h); version 1 carried 1 / M
+static constexpr uint32_t EVAL_BLOB_VERSION = 2;
 struct EvalBlobHeader { uint32_t magic, version; uint64_t total_bytes; dctfhe_params params; };
 static size_t eval_blob_size(const dctfhe_params& p) {
   size_t n = sizeof(EvalBlobHeader);
@@ -675,7 +677,7 @@ extern "C" int dctfhe_eval_keys_export(dctfhe_eval_keys* E, void* buf, size_t ca
   HIPCHK(hipSetDevice(E->ctx->device));
   HIPCHK(hipStreamSynchronize(E->ctx->stream));
   EvalBlobHeader h{};
-  h.magic = 0x4b564544u /* 'DEVK' */; h.version = 1; h.total_bytes = need; h.params = E->p;
+  h.magic = 0x4b564544u /* 'DEVK' */; h.version = EVAL_BLOB_VERSION; h.total_bytes = need; h.params = E->p;
   char* q = (char*)buf;
   memcpy(q, &h, sizeof h); q += sizeof h;
   for (int ti = 0; ti < E->p.n_tiers; ti++) {
@@ -694,7 +696,7 @@ extern "C" int dctfhe_eval_keys_import(dctfhe_ctx* ctx, const void* buf, size_t 
   if (size < sizeof(EvalBlobHeader)) return fail("evaluation-key blob too short");
   EvalBlobHeader h;
   memcpy(&h, buf, sizeof h);
-  if (h.magic != 0x4b564544u || h.version != 1) return fail("bad evaluation-key blob magic/version");
+  if (h.magic != 0x4b564544u || h.version != EVAL_BLOB_VERSION) return fail("bad evaluation-key blob magic/version");
   CHK(check_params(&h.params));
   if (h.total_bytes != size || eval_blob_size(h.params) != size) return fail("evaluation-key blob is %zu bytes, its parameters need %zu", size, eval_blob_size(h.params));
   std::unique_ptr<dctfhe_eval_keys> E;
@@ -891,6 +893,17 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
   return 0;
 }
 
+// centred mod switch on `count` small ciphertexts of tier `tier`, in place (kernels.h k_ms_center); part of the key-switch span of the timers
+static int dev_ms_center(dctfhe_keys* K, int tier, uint64_t* d_small, size_t count, Timers* tm) {
+  if (count == 0) return 0;
+  const dctfhe_tier& t = K->p.tiers[tier];
+  const int h = tm ? tm->begin(CAT_KS) : -1;
+  hipLaunchKernelGGL(k_ms_center, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, K->ctx->stream, d_small, count, t.n, t.logN);
+  HIPCHK(hipGetLastError());
+  if (tm) tm->end(h);
+  return 0;
+}
+
 static int dev_pbs(dctfhe_keys* K, int tier, const uint64_t* d_small, size_t count, const int64_t* d_tables, int w, const int32_t* d_idx,
                    int hw, int nchan, size_t e_offset, uint64_t* d_out, int accumulate, uint64_t body_add, Timers* tm, size_t L_out = 0) {
   const dctfhe_tier& t = K->p.tiers[tier];
@@ -962,11 +975,13 @@ static int dev_round_lut(dctfhe_keys* K, const StepTiers& stp, int tab_tier, con
     for (int i = 0; i < r; i++) {
       const int bt = stp.at(i);
       CHK(dev_keyswitch(K, bt, w0, cn, p - i, sc.digits, sc.bodies, sc.small, tm, deff, Lw));
+      CHK(dev_ms_center(K, bt, sc.small, cn, tm));
       const int vlog = 62 - p + i;
       CHK(dev_pbs(K, bt, sc.small, cn, sc.bit_tables + vlog, 0, nullptr, 1, 1, 0, w0, 1, (uint64_t)0 - (1ULL << vlog), tm, Lw));
     }
     if (r > 0) CHK(dev_keyswitch(K, tab_tier, w0, cn, 0, sc.digits, sc.bodies, sc.small, tm, deff, Lw));
     else       CHK(dev_keyswitch(K, tab_tier, d_src + c0 * Ls, cn, shift, sc.digits, sc.bodies, sc.small, tm, deff, Ls, body_add));
+    CHK(dev_ms_center(K, tab_tier, sc.small, cn, tm));
     CHK(dev_pbs(K, tab_tier, sc.small, cn, d_tables, w, d_idx ? d_idx + c0 : nullptr, hw, nchan, c0, w0, 0, 0, tm, Lw));
   }
   return 0;
@@ -1030,6 +1045,22 @@ extern "C" int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int
 }
 extern "C" int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, const uint64_t* cts, size_t count, int shift, uint64_t* cts_small) {
   return dctfhe_keyswitch_prefix(ctx, K, tier, cts, count, shift, 0, cts_small);
+}
+
+// the centred mod switch on host buffers (the scheduler applies it between every key switch and its bootstrap)
+extern "C" int dctfhe_modswitch_center(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, uint64_t* cts_small, size_t count) {
+  if (!ctx || !K || (count && !cts_small)) return fail("dctfhe_modswitch_center: null argument");
+  if (tier < 0 || tier >= K->p.n_tiers) return fail("tier out of range");
+  if (count == 0) return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(K->p.tiers[tier].n + 1) * 8;
+  DevBuf d;
+  HIPCHK(d.alloc(bytes));
+  HIPCHK(hipMemcpy(d.p, cts_small, bytes, hipMemcpyHostToDevice));
+  CHK(dev_ms_center(K, tier, d.as<uint64_t>(), count, nullptr));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(cts_small, d.p, bytes, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 extern "C" int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_eval_keys* K, int tier, const uint64_t* cts_small, size_t count, const int64_t* tables, int ntab,

@@ -475,24 +475,35 @@ inline void fill_twiddles(cplx* tw) {
   }
 }
 
-// double -> torus: the integer nearest to d, mod 2^64; exact for |d| < 2^116.
-// Split d = hi * 2^32 + lo with hi = rint(d / 2^32): lo and (hi mod 2^32) both lie in [-2^31, 2^31] and are exact in
-// f64, so adding 1.5 * 2^52 leaves their two's-complement value in the low mantissa bits -- no f64 -> i64 conversion
-// (which gfx950 expands to six f64 instructions) and no compare/select.  8 f64 + 2 integer instructions.
-HD uint64_t f64_to_torus(double d) {
-  const double hi = __builtin_rint(d * 2.3283064365386962890625e-10);                                   // 2^-32
-  const double lo = __builtin_fma(-hi, 4294967296.0, d);
-  const double h2 = __builtin_fma(-__builtin_rint(hi * 2.3283064365386962890625e-10), 4294967296.0, hi);
-  const double MAGIC = 6755399441055744.0;                                                              // 1.5 * 2^52
-  const uint64_t bl = __builtin_bit_cast(uint64_t, lo + MAGIC), bh = __builtin_bit_cast(uint64_t, h2 + MAGIC);
-  return (bl - 0x4338000000000000ULL) + (bh << 32);
+// ---- double -> torus.  The inverse transform hands over y in units of the WHOLE torus (1.0 = 2^64: the Fourier key carries 2^-64 / M),
+// so "mod 2^64" is the fractional part -- one v_fract_f64 -- and the words fall out of two conversions.  (Rounds 1-2 kept y in units of
+// 2^-64 and peeled the words off with rint / fma / magic-constant additions: 6 f64-rate instructions per 32-bit accumulator word and
+// 8 + 2 per 64-bit one, 12 % of the one-level N = 8192 kernel's issue slots; now 3 and 6.)
+HD double fract64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fract(x);            // v_fract_f64: x - floor(x), clamped below 1.0
+#else
+  const double r = x - __builtin_floor(x);     // (a tiny negative x would round to 1.0: the instruction clamps, so does this)
+  return r < 1.0 ? r : 0x1.fffffffffffffp-1;
+#endif
 }
-
-// the top 32 bits of the same value: round(d / 2^32) mod 2^32 (5 f64 instructions)
-HD uint32_t f64_to_torus32(double d) {
-  const double hi = __builtin_rint(d * 2.3283064365386962890625e-10);
-  const double h2 = __builtin_fma(-__builtin_rint(hi * 2.3283064365386962890625e-10), 4294967296.0, hi);
-  return (uint32_t)__builtin_bit_cast(uint64_t, h2 + 6755399441055744.0);
+// the top 32 bits of the torus value: round(frac(y) * 2^32), ROUNDED TO NEAREST -- a truncation here would bias every accumulator
+// coefficient the same way, and the bias of k N mask coefficients adds up coherently in the extracted phase.  frac(y) within 2^-33 of
+// 1 saturates to 2^32 - 1 instead of wrapping to 0: one unit of 2^-32, far below every tier's noise, probability 2^-33 per word.
+HD uint32_t f64_to_torus32(double y) {
+  const double x = __builtin_fma(fract64(y), 4294967296.0, 0.5);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)x;                          // v_cvt_u32_f64 (truncates, saturates)
+#else
+  return x >= 4294967296.0 ? 0xFFFFFFFFu : (uint32_t)x;
+#endif
+}
+// all 64 bits: floor(frac(y) * 2^64) (the truncation sits at 2^-64 of the torus, forty bits below the f64 transform's own error)
+HD uint64_t f64_to_torus(double y) {
+  const double x = fract64(y) * 4294967296.0;                  // < 2^32, exact
+  const uint32_t hi = (uint32_t)x;
+  const uint32_t lo = (uint32_t)(fract64(x) * 4294967296.0);
+  return ((uint64_t)hi << 32) | lo;
 }
 
 }  // namespace dctfhe

@@ -398,6 +398,26 @@ __global__ void k_ksk_colsum(const uint64_t* __restrict__ ksk, int R, int n, uin
   colsum[j] = s;
 }
 
+// Centred mod switch (semantics: oracle/tfhe_ref.c ref_ms_center).  The bootstrap rounds every word of the small ciphertext to 2N
+// levels; the evaluator knows each mask word's rounding remainder and that a key bit is 1 half of the time, so half the sum of the
+// remainders comes off the body first: the mod-switch error keeps sum_i (s_i - 1/2) e_i, half the variance.  One wave per ciphertext, in
+// place on the key switch's output, ~6.5 KB read per ciphertext.
+__global__ void __launch_bounds__(256) k_ms_center(uint64_t* __restrict__ small, size_t count, int n, int logN) {
+  const size_t c = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= count) return;
+  uint64_t* ct = small + c * (size_t)(n + 1);
+  const int sh = 63 - logN;
+  int64_t part = 0;
+  for (int i = lane; i < n; i += 64) {
+    const uint64_t a = ct[i];
+    const uint64_t at = ((a >> (sh - 1)) + 1) >> 1;
+    part += (int64_t)(a - (at << sh));
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) ct[n] -= (uint64_t)(part >> 1);
+}
+
 // ------------------------------------------------------------------------------------------ K4-K6 bootstrap
 struct pbs_launch {
   const uint64_t* cts_small;  // count x (n+1)

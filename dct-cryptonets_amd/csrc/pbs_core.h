@@ -679,8 +679,9 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
   }
 }
 
-// Forward transform of one standard-domain key polynomial into the device layout [j][t], with
-// the 1/M of the inverse transform folded in.  Thread t of a T-thread group.
+// Forward transform of one standard-domain key polynomial into the device layout [j][t], with the 1/M of the inverse transform and
+// the 2^-64 that puts the accumulator updates in units of the whole torus (fft_core.h, f64_to_torus*) folded in -- both exact scalings.
+// Thread t of a T-thread group.
 template <int LOGN, int P, class Sync, class WSync>
 HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* tw, cplx* exch, Sync&& sync, WSync&& wsync) {
   constexpr int N = 1 << LOGN, M = N / 2;
@@ -692,7 +693,7 @@ HD void key_poly_to_fourier(const uint64_t* poly, cplx* dst, int t, const cplx* 
     v[j] = cmk((double)(int64_t)poly[t + T * j], (double)(int64_t)poly[t + T * j + M]);
   });
   fft_forward<LOGN - 1, P>(v, t, tw, tw[F::TW_TOTAL + t], exch, sync, wsync);
-  const double inv = 1.0 / (double)M;
+  const double inv = 0x1p-64 / (double)M;
   static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; dst[j * T + t] = cmk(v[j].re * inv, v[j].im * inv); });
 }
 

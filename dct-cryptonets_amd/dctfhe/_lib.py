@@ -43,7 +43,7 @@ EXPORTS = [
     "dctfhe_ctx_synchronize", "dctfhe_keygen", "dctfhe_client_key_create", "dctfhe_client_key_destroy", "dctfhe_eval_keys_generate",
     "dctfhe_eval_keys_destroy", "dctfhe_eval_keys_export", "dctfhe_eval_keys_import", "dctfhe_client_key_export_secret",
     "dctfhe_eval_keys_export_ksk", "dctfhe_client_key_export_bsk", "dctfhe_rng_host", "dctfhe_rng_device", "dctfhe_client_key_set_encrypt_counter", "dctfhe_client_key_set_encrypt_nonce", "dctfhe_encrypt", "dctfhe_decrypt", "dctfhe_encrypt_rows", "dctfhe_decrypt_rows", "dctfhe_keyswitch", "dctfhe_keyswitch_prefix", "dctfhe_session_set_noise",
-    "dctfhe_pbs", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_add_rows", "dctfhe_affine_rows", "dctfhe_sum_pool_rows", "dctfhe_circuit_load", "dctfhe_circuit_destroy", "dctfhe_params_check", "dctfhe_circuit_validate", "dctfhe_dct_frontend",
+    "dctfhe_pbs", "dctfhe_modswitch_center", "dctfhe_round_lut", "dctfhe_conv2d", "dctfhe_add_rows", "dctfhe_affine_rows", "dctfhe_sum_pool_rows", "dctfhe_circuit_load", "dctfhe_circuit_destroy", "dctfhe_params_check", "dctfhe_circuit_validate", "dctfhe_dct_frontend",
     "dctfhe_circuit_stats", "dctfhe_circuit_io", "dctfhe_session_create", "dctfhe_session_destroy",
     "dctfhe_session_upload", "dctfhe_session_run", "dctfhe_session_download", "dctfhe_session_upload_rows", "dctfhe_session_download_rows", "dctfhe_session_dims", "dctfhe_fp64_peak", "dctfhe_bench_pbs",
 ]
@@ -91,6 +91,7 @@ def load():
     L.dctfhe_keyswitch.argtypes = [vp, vp, i32, vp, sz, i32, vp]
     L.dctfhe_session_set_noise.argtypes = [vp, C.c_uint64, vp, i32]
     L.dctfhe_keyswitch_prefix.argtypes = [vp, vp, i32, vp, sz, i32, i32, vp]
+    L.dctfhe_modswitch_center.argtypes = [vp, vp, i32, vp, sz]
     L.dctfhe_pbs.argtypes = [vp, vp, i32, vp, sz, vp, i32, i32, vp, vp]
     L.dctfhe_round_lut.argtypes = [vp, vp, i32, i32, vp, sz, i32, i32, vp, i32, i32, vp, vp]
     L.dctfhe_conv2d.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp]

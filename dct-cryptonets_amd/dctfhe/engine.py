@@ -211,6 +211,12 @@ class EvalKeys:
         check(self.L.dctfhe_keyswitch_prefix(self.ctx.h, self.h, tier, ptr(cts), cts.shape[0], shift, deff, ptr(out)))
         return out
 
+    def modswitch_center(self, tier, cts_small):
+        """centred mod switch (dctfhe_modswitch_center): the adjusted copy of small ciphertexts [count, n + 1]"""
+        out = np.ascontiguousarray(cts_small, np.uint64).copy()
+        check(self.L.dctfhe_modswitch_center(self.ctx.h, self.h, tier, ptr(out), out.shape[0]))
+        return out
+
     def pbs(self, tier, cts_small, tables, w, table_idx=None):
         cts_small = np.ascontiguousarray(cts_small, np.uint64)
         tables = np.ascontiguousarray(tables, np.int64).reshape(-1, 1 << w)
@@ -259,7 +265,7 @@ class Keys:
     def __getattr__(self, name):
         if name in ("export_secret", "export_bsk", "encrypt", "decrypt", "seed", "input_dim", "set_encrypt_nonce", "set_encrypt_counter"):
             return getattr(self.client, name)
-        if name in ("export_ksk", "keyswitch", "pbs", "round_lut", "bench_pbs", "to_blob"):
+        if name in ("export_ksk", "keyswitch", "modswitch_center", "pbs", "round_lut", "bench_pbs", "to_blob"):
             return getattr(self.eval, name)
         raise AttributeError(name)
 

@@ -89,8 +89,11 @@ def var_keyswitch(D_eff, t):
     return D_eff * t.lk * ((B * B + 2) / 12.0) * t.lwe_sigma ** 2 + (D_eff / 2.0) * 2.0 ** (-2 * t.betak * t.lk) / 12.0
 
 
-def var_modswitch(t):
-    return (t.n / 2.0 + 1.0) / (48.0 * t.N ** 2)
+def var_modswitch(t, centred=True):
+    """rounding every word of the small ciphertext to 2N levels: sum_i s_i e_i + e_b with e uniform on +-1/(4N).  The engine's mod
+    switch is CENTRED (csrc/kernels.h k_ms_center, oracle ref_ms_center): half the sum of the known remainders e_i comes off the body,
+    leaving sum_i (s_i - 1/2) e_i -- n/4 units instead of the n/2 of the plain form (binary key, half the bits set)."""
+    return ((t.n / 4.0 if centred else t.n / 2.0) + 1.0) / (48.0 * t.N ** 2)
 
 
 def var_pbs_out(t, fft_c=2.0):
@@ -121,8 +124,9 @@ def p_fail(margin, var):
 def default_params():
     """Exact-evaluation set: every table site fails with probability < 1e-12 under the model above.
 
-    Small-key lengths: n = 808 for the 5/6-bit table tiers, 768 / 728 for the 4-bit ones and 560 for the one-bit tiers are the
-    smallest (in steps of 8) that keep every site of the benchmark circuits under that budget with base-4 key-switch gadgets
+    Small-key lengths: n = 800 for the 5/6-bit table tiers, 760 / 720 for the 4-bit ones and 560 for the one-bit tiers are the
+    smallest (in steps of 8) that keep every site of the benchmark circuits under that budget (tools/param_search.py ->
+    profiles/r03_param_search.log; round 3's centred mod switch bought the last 8 bits of each table tier) with base-4 key-switch gadgets
     (below) and a key switch that sums only over the effective dimension of its input (2048 for everything downstream of a
     refresh or of the client, who encrypts under the first 2048 key bits: input_dim); the blind rotation is linear in n.
 
@@ -138,30 +142,30 @@ def default_params():
     # ciphertext).  The one-bit tiers (half-box 1/4) take base 4 at the SAME depth, five levels: only the top 10 bits of a mask word are
     # switched, the truncation (sigma 2^-6.8) stays below the key noise (2^-5.4), the gadget factor drops from 27.5 to 7.5 -- which buys
     # 24 key bits (560 instead of 584) and lets the two-bit-rotation tier Ba2 take every step Ba used to run (ResNet-20, ResNet-18 3x32^2).
-    t6 = TierSpec("T6", n=808, k=1, logN=13, l=3, beta=11, lk=9, betak=2)
+    t6 = TierSpec("T6", n=800, k=1, logN=13, l=3, beta=11, lk=9, betak=2)
     # T4 / T4r look up 4-bit values (half-box 2^-6, four times the 6-bit tiers'): they afford a shorter small key -- and the
     # blind rotation is linear in n -- at the price of key-switch keys of their own (prefixes of the same small key, noise of
     # their own dimension).  752 / 792 are the smallest (steps of 8) that keep every site of the benchmark circuits at the
     # worst-site level of the 832-bit tiers (tools: the search behind profiles/r02_param_search.log).
-    t4 = TierSpec("T4", n=728, k=1, logN=11, l=1, beta=23, lk=9, betak=2, unroll=2)
+    t4 = TierSpec("T4", n=720, k=1, logN=11, l=1, beta=23, lk=9, betak=2, unroll=2)
     b = TierSpec("B", n=560, k=2, logN=10, l=2, beta=14, lk=5, betak=2)
     # T6a: same ring and input margin as T6, one level: its output (sigma ~2^-13) only ever meets the 2^-7 half-box
     # of the residual-sum table, never a convolution.  Half the transforms of T6 for half of the 6-bit sites.
-    t6a = TierSpec("T6a", n=808, k=1, logN=13, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
+    t6a = TierSpec("T6a", n=800, k=1, logN=13, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
     # Ba: one-level bit tier.  The output of rounding step i is amplified by 2^(p-j) only in the later steps j > i,
     # so the later steps of a chain tolerate sigma ~2^-15; the compiler picks, per
     # site, the first step from which Ba is safe.
     ba = TierSpec("Ba", n=560, k=2, logN=10, l=1, beta=23, lk=5, betak=2, ksk_share=3)
     # T4r: small ring, three levels: turns the noisy 4-bit output of a T6a look-up into a convolution-grade ciphertext
     # (sigma ~2^-25).  T6a + T4r costs ~0.7x of one T6 bootstrap.
-    t4r = TierSpec("T4r", n=768, k=1, logN=11, l=3, beta=12, lk=9, betak=2)
+    t4r = TierSpec("T4r", n=760, k=1, logN=11, l=3, beta=12, lk=9, betak=2)
     # T4r2: the same refresh with two key bits per iteration (general form of the two-bit rotation, csrc/pbs_core.h): 10 %
     # fewer milliseconds per launch, output 0.7 bit noisier (three external products per pair).  The compiler takes it when every
     # site of the circuit stays inside the budget with it (the ResNet-20 circuits do) and falls back to T4r otherwise (two
     # sites of ResNet-18 3x32^2 would sit at 3.8e-12): ParamSet.table_tier_fallback_for_w.  Shares T4r's key-switch key.
-    t4r2 = TierSpec("T4r2", n=768, k=1, logN=11, l=3, beta=12, lk=9, betak=2, ksk_share=1, unroll=2)
+    t4r2 = TierSpec("T4r2", n=760, k=1, logN=11, l=3, beta=12, lk=9, betak=2, ksk_share=1, unroll=2)
     # T5a: one-level twin of the three-level 5-bit tier; the 5-bit residual-sum table is split the same way (T5a + T4r)
-    t5a = TierSpec("T5a", n=808, k=1, logN=12, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
+    t5a = TierSpec("T5a", n=800, k=1, logN=12, l=1, beta=22, lk=9, betak=2, ksk_share=0, unroll=2)
     # (a table of 5 or 6 input bits that feeds a convolution without the split would run on T6; with refresh_min_w = 5 none does)
     # Ba2: the one-level bit tier on the general two-bit rotation: 49.7 ms per launch of 16 384 against 63.6 (profiles/r02_exp_ablations.log),
     # output 0.5 bit noisier (2^-14.5): the compiler gives it the steps of a chain that can take that (78 % of them), Ba the ones before.

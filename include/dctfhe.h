@@ -155,6 +155,10 @@ int dctfhe_keyswitch(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const ui
  * dimension k*N <= deff): only the first deff rows of the key are used -- identical result, deff/D of the work */
 int dctfhe_keyswitch_prefix(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts, size_t count,
                             int shift, int deff, uint64_t* cts_small);
+/* centred mod switch, in place on small ciphertexts (count x (n+1)): half the sum of the mask words' rounding remainders comes off the
+ * body, which halves the variance of the bootstrap's mod-switch error.  dctfhe_round_lut and dctfhe_session_run
+ * apply it between every key switch and its bootstrap; dctfhe_keyswitch / dctfhe_pbs are the bare primitives. */
+int dctfhe_modswitch_center(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, uint64_t* cts_small, size_t count);
 int dctfhe_pbs(dctfhe_ctx* ctx, dctfhe_eval_keys* keys, int tier, const uint64_t* cts_small, size_t count,
                const int64_t* tables /* [ntab][2^w] */, int ntab, int w, const int32_t* table_idx /* may be NULL */,
                uint64_t* cts_out /* count x (D+1) */);

@@ -49,6 +49,7 @@ def lib():
     L.ref_bsk_to_fourier.argtypes = [u64p, C.c_int, C.c_int, C.c_int, C.c_int, f64p]
     L.ref_keyswitch.argtypes = [u64p, C.c_int, C.c_int, u64p, C.c_int, C.c_int, C.c_int, u64p]
     L.ref_modswitch.argtypes = [u64p, C.c_int, C.c_int, u32p]
+    L.ref_ms_center.argtypes = [u64p, C.c_int, C.c_int, C.c_int]
     L.ref_decompose.argtypes = [C.c_uint64, C.c_int, C.c_int, i32p]
     L.ref_build_testvector.argtypes = [i64p, C.c_int, C.c_int, u64p]
     L.ref_pbs_batch.argtypes = [u64p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -130,6 +131,13 @@ def pbs(cts_small, bsk_f, bsk, k, N, l, beta, tables, w, table_idx, D_out, exact
                         None if bsk_f is None else bsk_f.ctypes.data, None if bsk is None else bsk.ctypes.data,
                         1 if exact else 0, k, N, l, beta, tables, w,
                         None if idx is None else idx.ctypes.data, D_out, out)
+    return out
+
+
+def ms_center(cts_small, N):
+    """centred mod switch (ref_ms_center): returns the adjusted copy"""
+    out = np.ascontiguousarray(cts_small, np.uint64).copy()
+    lib().ref_ms_center(out, out.shape[0], out.shape[1] - 1, N)
     return out
 
 

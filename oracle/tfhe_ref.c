@@ -156,6 +156,25 @@ void ref_modswitch(const uint64_t *ct_small, int n, int N, uint32_t *out) {
   for (int i = 0; i <= n; i++) out[i] = (uint32_t)(((ct_small[i] >> sh) + 1) >> 1) & mask;
 }
 
+/* Centred ("mean-compensated") mod switch, applied to a small ciphertext BEFORE ref_modswitch: the rounding error of mask word i,
+ * e_i = a_i 2N/q - round(a_i 2N/q), enters the switched phase as sum_i s_i e_i.  The evaluator knows every e_i and E[s_i] = 1/2, so it
+ * takes (1/2) sum_i e_i off the body; what is left is sum_i (s_i - 1/2) e_i: variance n / (192 N^2) instead of n / (96 N^2)
+ * (binary keys; [K] standard trick, e.g. the "mean compensation" of the TFHE parameter literature).  In place, integer arithmetic. */
+void ref_ms_center(uint64_t *cts_small, int count, int n, int N) {
+  int logN = 0;
+  while ((1 << logN) < N) logN++;
+  const int sh = 63 - logN;
+  for (int c = 0; c < count; c++) {
+    uint64_t *ct = cts_small + (size_t)c * (n + 1);
+    int64_t R = 0;
+    for (int i = 0; i < n; i++) {
+      const uint64_t at = ((ct[i] >> (sh - 1)) + 1) >> 1;          /* round(a / 2^sh), as ref_modswitch before its mask */
+      R += (int64_t)(ct[i] - (at << sh));                         /* signed remainder, |.| <= 2^(sh-1) */
+    }
+    ct[n] -= (uint64_t)(R >> 1);
+  }
+}
+
 /* ------------------------------------------------------------------ negacyclic helpers */
 /* out = X^r * in  in Z[X]/(X^N+1), 0 <= r < 2N */
 static void nega_rotate(uint64_t *out, const uint64_t *in, int r, int N) {

@@ -64,6 +64,8 @@ void ref_bsk_to_fourier(const uint64_t *bsk, int n, int k, int N, int l, double 
 void ref_keyswitch(const uint64_t *cts_in, int count, int D, const uint64_t *ksk, int n, int lk,
                    int betak, uint64_t *cts_out /* count x (n+1) */);
 void ref_modswitch(const uint64_t *ct_small, int n, int N, uint32_t *out /* n+1, in [0,2N) */);
+/* centred mod switch: body -= (1/2) sum of the mask words' rounding remainders (in place, before ref_modswitch / a bootstrap) */
+void ref_ms_center(uint64_t *cts_small, int count, int n, int N);
 void ref_decompose(uint64_t v, int l, int beta, int32_t *digits /* l, lev 0 first */);
 void ref_build_testvector(const int64_t *table, int w, int N, uint64_t *tv);
 

@@ -151,26 +151,31 @@ static int fft_case() {
 }
 
 // ---- the integer/f64 helpers the kernels lean on, against independent definitions
-static int torus_case() {     // f64 -> torus: the integer nearest to d, mod 2^64 (and its top 32 bits), |d| < 2^116
+static int torus_case() {     // y (units of the whole torus) -> floor(frac(y) 2^64), and round(frac(y) 2^32) saturating at 2^32 - 1, against 128-bit integers
   uint64_t st = 5; int bad = 0;
   for (int it = 0; it < 4000000; it++) {
-    const int e = (int)(ref_splitmix64(&st) % 118) - 2;
-    double d = std::ldexp((double)(int64_t)ref_splitmix64(&st) / 9223372036854775808.0, e);
-    if (it % 7 == 0) d = std::nearbyint(d) + ((it % 3) ? 0.0 : 0.5);
-    const double r = std::nearbyint(d);
-    uint64_t want = 0;
-    if (r != 0) {
-      int ex; const double m = std::frexp(r, &ex);
-      const __int128 mant = (__int128)std::ldexp(m, 53);
-      const bool neg = mant < 0; const unsigned __int128 a = neg ? (unsigned __int128)(-mant) : (unsigned __int128)mant;
-      const int sh = ex - 53;
-      const unsigned __int128 v = sh >= 0 ? (sh >= 128 ? 0 : a << sh) : a >> (-sh);
-      want = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-    }
-    if (f64_to_torus(d) != want) bad++;
-    // top half: round(d / 2^32) mod 2^32 -- differs from want >> 32 only by the carry of the rounding
-    const uint32_t t32 = f64_to_torus32(d), lo = (uint32_t)(want >> 32);
-    if (t32 != lo && t32 != lo + 1u) bad++;
+    const int e = (int)(ref_splitmix64(&st) % 118) - 66;                      // |y| from 2^-66 to 2^52
+    double y = std::ldexp((double)(int64_t)ref_splitmix64(&st) / 9223372036854775808.0, e);
+    if (it % 7 == 0) y = std::nearbyint(y) + ((it % 3) ? 0.0 : 0.5);
+    if (it % 13 == 0) y = std::ldexp((double)(int64_t)(ref_splitmix64(&st) >> 11), -53) * ((it & 1) ? 1.0 : -1.0);   // 53-bit fractions
+    // exact frac(y) * 2^64 from the mantissa: y = mant * 2^(ex - 53)
+    int ex; const double m = std::frexp(y, &ex);
+    const __int128 mant = (__int128)std::ldexp(m, 53);                        // signed 53-bit integer
+    const int sh = ex - 53 + 64;                                              // y * 2^64 = mant * 2^sh
+    unsigned __int128 v;                                                      // floor(y * 2^64) mod 2^64
+    if (sh >= 0) v = sh >= 64 ? 0 : (unsigned __int128)((__int128)mant << sh);
+    else if (sh <= -64) v = mant < 0 ? ~(unsigned __int128)0 : 0;
+    else v = (unsigned __int128)(mant >> (-sh));                              // arithmetic shift = floor
+    const uint64_t want = (uint64_t)v;
+    // exact for y >= 0; a negative y takes its fractional part as 1 - |frac|, which rounds to f64's grid below 1.0: 2^-53 of the torus
+    const uint64_t got = f64_to_torus(y);
+    const int64_t diff = (int64_t)(got - want);
+    if (y >= 0 ? diff != 0 : (diff > 2048 || diff < -2048)) bad++;
+    // top half, rounded to nearest: floor(frac * 2^32 + 1/2), saturating
+    const uint64_t r = (want >> 32) + ((want >> 31) & 1);
+    const uint32_t want32 = r >= (1ULL << 32) ? 0xFFFFFFFFu : (uint32_t)r;
+    const uint32_t t32 = f64_to_torus32(y);
+    if (t32 != want32) bad++;
   }
   std::printf("f64_to_torus: %d mismatches\n", bad);
   return bad != 0;

@@ -52,6 +52,32 @@ def test_shard_gather_matches_serial(tmp_path):
     assert got["tmax"].item() == 2.0
 
 
+def _worker_helpers(rank, world, port, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "dct-cryptonets_amd"))
+    from dctfhe.sharding import agree_min, all_true, barrier, broadcast_seed, max_over_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    seed = broadcast_seed(bytes([rank + 1] * 32), world, dev)              # every rank ends with rank 0's bytes
+    plan = agree_min([5 - rank, 20 + rank], world, dev)                    # the tightest plan wins
+    tmax = max_over_ranks(10.0 + rank, world, dev)
+    ok_all, ok_one = all_true(True, world, dev), all_true(rank == 0, world, dev)
+    barrier(world)
+    if rank == 1:
+        torch.save({"seed": list(seed), "plan": plan, "tmax": tmax, "ok_all": ok_all, "ok_one": ok_one}, out_path)
+    dist.destroy_process_group()
+
+
+def test_bench_collectives_world_size_two(tmp_path):
+    """the helpers bench.py calls for its seed broadcast, pass plan, max-over-ranks timing and exactness flag (dctfhe/sharding.py), seen
+    from rank 1 of a two-rank gloo group; tests/test_gpu_rccl_smoke.py runs the same calls on RCCL"""
+    out = str(tmp_path / "helpers.pt")
+    mp.spawn(_worker_helpers, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert got["seed"] == [1] * 32 and got["plan"] == [4, 20] and got["tmax"] == 11.0 and got["ok_all"] is True and got["ok_one"] is False
+
+
 def test_shard_indices_partition():
     sys.path.insert(0, os.path.join(ROOT, "dct-cryptonets_amd"))
     from dctfhe.sharding import shard_indices

@@ -214,3 +214,46 @@ def test_imported_checkpoint_runs_encrypted(tmp_path):
         assert np.array_equal(qm.forward_quantized(q, "execute"), _oracle_out(qm, q))
     finally:
         qm.close()
+
+
+def test_rounding_chain_on_a_key_switch_that_cannot_narrow():
+    """a rounding chain works in place on a shifted copy of its input of which only the first `deff` mask words used to be
+    written; a key switch that cannot narrow to `deff` (betak = 8 runs the integer-VALU GEMM, which walks the whole row) then read
+    whatever the recycled buffer held beyond them.  Here: table ring = D = 1024, client encryption on a 512-word prefix (input_dim),
+    bit tier ring 512 -- so every work row has 512 meaningful mask words in 1024 -- and betak = 8 on both tiers.  Two passes over one
+    upload (the second finds the first's leftovers in every buffer), all outputs equal to the integer circuit."""
+    from dctfhe import models, params as P
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    t_tab = P.TierSpec("t", n=48, k=1, logN=10, l=2, beta=12, lk=3, betak=8, lwe_sigma=2.0 ** -28, glwe_sigma=2.0 ** -48)
+    t_bit = P.TierSpec("b", n=40, k=2, logN=8, l=2, beta=10, lk=3, betak=8, lwe_sigma=2.0 ** -26, glwe_sigma=2.0 ** -48)
+    ps = P.ParamSet(D=1024, tiers=[t_tab, t_bit], bit_tier=1, table_tier_for_w={6: 0}, input_sigma=2.0 ** -55, input_dim=512)
+    rng = np.random.default_rng(0)
+    calib = rng.normal(0, 1, (48, 4, 6, 6))
+    qm = compile_brevitas_qat_model(models.tiny_resnet_q(), calib, n_bits=5, rounding_threshold_bits=6, param_set=ps)
+    try:
+        assert any(o.type == 4 and o.r > 0 for o in qm.compiled.ops)            # rounding chains are what this is about
+        qm.fhe_circuit.keygen(seed=8)
+        q = qm.quantize_input(calib[:4])
+        want = _oracle_out(qm, q)
+        sess = qm._session("execute", 4)
+        in_dim, out_dim = sess.dims()
+        assert in_dim == out_dim == 1024                                        # a VALU-path tier keeps every tensor at full width
+        sess.upload(qm._keys.encrypt(qm.encode_input(q).reshape(-1), 512), 512)
+        for _ in range(2):
+            sess.run()
+            out = sess.download(out_dim).reshape(-1, out_dim + 1)
+            assert np.array_equal(qm.decode_output(qm._keys.decrypt(out, out_dim).reshape(4, -1)), want)
+        assert np.array_equal(qm.forward_quantized(q, "execute"), want)
+    finally:
+        qm.close()
+
+
+def test_fhe_circuit_statistics_is_a_property(tiny):
+    """Concrete's `fhe_circuit.statistics` is a property (a paste had turned it into a plain method and left dead copies of
+    the owner's key methods on FHECircuit)"""
+    from dctfhe.quantized_module import FHECircuit
+    qm, _ = tiny
+    assert isinstance(FHECircuit.statistics, property)
+    st = qm.fhe_circuit.statistics
+    assert st.n_ops == len(qm.compiled.ops) and st.lut_sites > 0 and st.max_bit_width == qm.compiled.max_bit_width
+    assert callable(qm.fhe_circuit.export_evaluation_keys) and callable(qm.fhe_circuit.load_evaluation_keys)

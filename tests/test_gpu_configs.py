@@ -1,12 +1,12 @@
 """Every BASELINE config as a parity case on the encrypted HIP path.
   * clear-mode circuit (1-word ciphertexts on the GPU scheduler) against the numpy integer circuit, configs #3 and #4;
   * ENCRYPTED, full-size exact tiers, decrypt(run(encrypt(q))) == integer circuit on every output:
-      #2  ResNet-20 24x16^2, two images in one batch           (tests/test_gpu_resnet20.py)
+      #2  ResNet-20 24x16^2, the 8-image batch in one session  (tests/test_gpu_resnet20.py)
       #3  ResNet-20 3x32^2, one image (256 outputs)
       #4  ResNet-18 3x32^2, one image (512 outputs)
-      #5  ResNet-18 48x112^2: one full-size image is ~9 minutes, so a circuit PREFIX -- the 1x1 stem without ReLU
-          (reference models/backbone.py:555-563 `relu1: False`) and the first stage of two 64-channel blocks -- on a
-          16x16 crop of the 112x112 DCT planes, same tiers, same per-site precisions.
+      #5  ResNet-18 48x112^2: one full-size image is ~8 minutes, so (i) the WHOLE trunk -- 1x1 stem without ReLU (reference
+          models/backbone.py:555-563 `relu1: False`) and all four stages -- on a 56x56 crop of the 112x112 DCT planes (a quarter of
+          the image), and (ii) the stem + first stage on a 16x16 crop under catalogue variants; same tiers, same per-site precisions.
 The label check uses the seeded classifier centred on the calibration features (dctfhe.synthetic.centre_classifier):
 labels differ between images, so comparing them checks something."""
 import numpy as np
@@ -87,6 +87,33 @@ def test_encrypted_config5_prefix_bit_exact():
         qm.fhe_circuit.keygen(seed=1)
         got = qm.forward_quantized(q, "execute")
         assert np.array_equal(got, want), (got, want)
+    finally:
+        qm.close()
+
+
+def test_encrypted_config5_whole_trunk_on_a_crop_bit_exact():
+    """#5 ResNet-18 48x112^2, ALL FOUR STAGES (round 2 stopped after stage 1): the 1x1 48->64 stem without ReLU (reference
+    models/backbone.py:555-563), the two 64-channel blocks, then the stride-2 3x3 convolutions and 1x1 stride-2 shortcuts into 128, 256
+    and 512 channels -- on a 56x56 crop of the 112x112 DCT planes (a quarter of the image: ~13 M bootstraps), pooling window 7 on the
+    final 7x7 map instead of 14 on 14x14, same tiers and per-site precisions.  Every one of the 512 outputs equals the integer circuit."""
+    from dctfhe import frontend, models, synthetic
+    from dctfhe.quantized_module import compile_brevitas_qat_model
+    tf = frontend.dct_eval_transform(filter_size=8, image_size_dct=112, channels=48)
+    planes = np.stack([tf(im) for im in synthetic.synthetic_images(13, 7, size=96)]).astype(np.float32)     # [13, 48, 112, 112]
+    crops = planes[:, :, 28:84, 28:84]
+    model = models.ResNet18QAT(bit_width=4, in_channels=48, img_size=112)
+    assert len(model.blocks) == 8 and [b.C1.stride for b in model.blocks] == [1, 1, 2, 1, 2, 1, 2, 1]
+    assert [b.shortcut is not None for b in model.blocks] == [False, False, True, False, True, False, True, False]
+    whole = models.trunk_prefix(model, n_blocks=8, avgpool_kernel=7)
+    qm = compile_brevitas_qat_model(whole, crops[:12], n_bits=5, rounding_threshold_bits=6, p_error=0.01)
+    try:
+        assert qm.compiled.n_out() == 512
+        q = qm.quantize_input(crops[12:13])
+        want = _oracle(qm, q)
+        assert want.shape == (1, 512) and len(np.unique(want)) > 4
+        qm.fhe_circuit.keygen(seed=1)
+        got = qm.forward_quantized(q, "execute")
+        assert np.array_equal(got, want), np.argwhere(got != want)
     finally:
         qm.close()
 

@@ -68,3 +68,51 @@ def test_keyswitch_noise_matches_model(gpu_ctx, oracle):
         print("sigma after key switch log2 (measured, model):", report)
     finally:
         keys.close()
+
+
+def test_centred_mod_switch_halves_the_rounding_noise(gpu_ctx, oracle):
+    """k_ms_center (the scheduler runs it between every key switch and its bootstrap): bit-exact against the oracle's ref_ms_center, and the
+    error of the switched phase -- b~ - sum a~_i s_i against the exact phase, in units of the 2N levels -- has the variance the compiler
+    budgets with: n/4 + 1 twelfths per level^2 centred against n/2 + 1 plain (params.var_modswitch), measured with the real small key
+    on key-switched ciphertexts of the 6-bit tier's shape (N = 8192, n = 800) and of the one-bit tiers' (N = 1024, n = 560)."""
+    from dctfhe import params as P
+    from dctfhe.engine import Keys
+    ps = P.default_params()
+    keys = Keys(gpu_ctx, P.to_c_params(ps), seed=9)
+    try:
+        _, s = keys.export_secret()
+        rng = np.random.default_rng(2)
+        msgs = rng.integers(0, 16, 4096).astype(np.uint64) << np.uint64(59)
+        cts = keys.encrypt(msgs)
+        names = [t.name for t in ps.tiers]
+        for name in ("T6a", "Ba2"):
+            ti = names.index(name)
+            t = ps.tiers[ti]
+            small = keys.keyswitch(ti, cts)
+            centred = keys.modswitch_center(ti, small)
+            assert np.array_equal(centred, oracle.ms_center(small, t.N))                       # integer arithmetic: bit for bit
+            assert np.array_equal(centred[:, :t.n], small[:, :t.n]) and np.any(centred[:, t.n] != small[:, t.n])
+            sk = s[:t.n].astype(np.int64)
+            sh = np.uint64(63 - t.logN)
+
+            def switched_phase_error(c):
+                lv = ((c >> (sh - np.uint64(1))) + np.uint64(1)) >> np.uint64(1)               # round(word / 2^sh): the 2N levels (before the mask)
+                exact = (c[:, t.n] - (c[:, :t.n] * sk.astype(np.uint64)).sum(axis=1, dtype=np.uint64)).astype(np.uint64)
+                coarse = ((lv[:, t.n] - (lv[:, :t.n] * sk.astype(np.uint64)).sum(axis=1, dtype=np.uint64)) << sh).astype(np.uint64)
+                return _cent(coarse - exact) * 2.0 * t.N                                       # in levels
+
+            e_plain = switched_phase_error(small)
+            # the centred body differs from the plain one by R/2: compare its switched phase with the ORIGINAL exact phase
+            lv = ((centred >> (sh - np.uint64(1))) + np.uint64(1)) >> np.uint64(1)
+            exact = (small[:, t.n] - (small[:, :t.n] * sk.astype(np.uint64)).sum(axis=1, dtype=np.uint64)).astype(np.uint64)
+            coarse = ((lv[:, t.n] - (lv[:, :t.n] * sk.astype(np.uint64)).sum(axis=1, dtype=np.uint64)) << sh).astype(np.uint64)
+            e_cent = _cent(coarse - exact) * 2.0 * t.N
+            h = int(sk.sum())
+            v_plain, v_cent = (h + 1) / 12.0, (t.n / 4.0 + 1) / 12.0                            # per level^2 (the model assumes h = n/2)
+            assert 0.85 * v_plain < e_plain.var() < 1.15 * v_plain, (name, e_plain.var(), v_plain)
+            assert 0.85 * v_cent < e_cent.var() < 1.15 * v_cent, (name, e_cent.var(), v_cent)
+            assert abs(e_cent.mean()) < 4 * math.sqrt(v_cent / e_cent.size) + 0.6                # |h - n/2| leaves a small mean: (h - n/2) E[e] = 0
+            model = P.var_modswitch(t) * (2.0 * t.N) ** 2
+            assert abs(model - v_cent) < 1e-9
+    finally:
+        keys.close()

@@ -24,7 +24,7 @@ void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   for (int m = 0; m < 8; m++) wtab[2 * N + m] = root64(8 * m);
   std::vector<cplx> bsk(bsk_elems);
   uint64_t st = 1;
-  for (auto& c : bsk) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; c.re = (double)(int64_t)st / M; st = st * 6364136223846793005ULL + 1; c.im = (double)(int64_t)st / M; }
+  for (auto& c : bsk) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; c.re = (double)(int64_t)st * 0x1p-64 / M; st = st * 6364136223846793005ULL + 1; c.im = (double)(int64_t)st * 0x1p-64 / M; }
   std::vector<uint64_t> small(count * (n + 1));
   for (auto& v : small) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; v = st; }
   int64_t tab[16]; for (int i = 0; i < 16; i++) tab[i] = (int64_t)i << 58;
