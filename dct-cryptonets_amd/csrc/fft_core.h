@@ -162,9 +162,23 @@ struct fft_geom {
   static constexpr int tw_offset(int i) { return geom_tw_offset(LOGM, P, i); }
   static constexpr int TW_TOTAL = geom_tw_offset(LOGM, P, S - 1);  // then T twist bases e^{i pi t/N}
   static constexpr int TW_ELEMS = TW_TOTAL + T;
-  // exchange buffer index skew (bank spreading), LDS holds EXCH_ELEMS complex values
-  // one padding element per P: conflict-free writes and at most 2-way reads on the first exchange (model: tools/lds_model.py)
+  // Two images of the exchange buffer (LDS holds EXCH_ELEMS complex values either way), chosen PER EXCHANGE by the pattern that READS it.
+  // gfx950 serves a wave's ds_read_b128 in four groups of 16 non-contiguous lanes over 64 banks and its ds_write_b128 in eight groups of
+  // 8 contiguous lanes over 32 banks (MI355X_MICROARCH.md, LDS; model: tools/lds_model.py).  Every write pattern of the transforms is
+  // conflict-free under both images; the reads differ:
+  //   skew   one padding element per P: conflict-free for the strided gathers (weight < 16 lanes, or the last, smaller radix), 2-way
+  //          for the lane-contiguous ones (16 contiguous elements then span 17 slots);
+  //   swz    no padding, the element's position inside its row of 8 XORed with the row number: conflict-free for the lane-contiguous
+  //          gathers (weight >= 16), 2-way for the strided ones.  Kept inside the same per-wave footprint as `skew` (512 elements of a
+  //          wave's block -> 576 slots), so that a wave-local exchange never touches another wave's slots whichever image it uses.
+  // Round 2 used `skew` throughout: 1.07 conflict cycles per LDS instruction on the N = 8192 kernel (profiles/r02_pmc_tiers*.txt), all of
+  // them on the three lane-contiguous gathers of a forward + inverse pair -- the model's count exactly.
   static HD int skew(int idx) { return idx + (idx >> geom_logp(P)); }
+  static HD int swz(int idx) { return (idx >> 9) * 576 + ((idx & 511) ^ ((idx >> 3) & 7)); }
+  // (M = 512, one wave per ciphertext: a single gather would gain and the second set of addresses costs the k = 2 kernels registers they
+  //  do not have -- 60-84 bytes of scratch per lane, +1 / +4 % time: profiles/r03_exp_lds_image.log -- so those keep `skew` throughout)
+  static constexpr bool swz_reader(int i) { return P == 8 && LOGM >= 10 && geom_radix(LOGM, P, i) == P && geom_weight(LOGM, P, i) >= 16; }
+  template <int IR> static HD int ex(int idx) { if constexpr (swz_reader(IR)) return swz(idx); else return skew(idx); }   // IR: the pass that gathers
   static constexpr int EXCH_ELEMS = M + (M >> geom_logp(P));
 };
 
@@ -233,9 +247,9 @@ HD void fft_forward(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch
       // The gather itself, and everything a wave-local exchange touches, stays inside the wave's own block,
       // where program order (the LDS queue of a wave is in order) is enough.
       if constexpr (W <= 64) wsync(); else sync();
-      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::template ex<i + 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
       if constexpr (W <= 64) wsync(); else sync();
-      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::template ex<i + 1>(pass_addr<LOGM, P, i + 1>(t, j))]; });
     } else {
       static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = y[j]; });
     }
@@ -271,9 +285,9 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch
     }
     if constexpr (i > 0) {
       constexpr int Wp = G::weight(i - 1);   // exchange between pass i-1 and i: groups of W_{i-1} threads
-      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; exch[G::template ex<i - 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
       if constexpr (Wp <= 64) wsync(); else sync();
-      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
+      static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[j] = exch[G::template ex<i - 1>(pass_addr<LOGM, P, i - 1>(t, j))]; });
       // after a cross-wave gather other waves may still be reading this wave's block: barrier before anyone writes again
       if constexpr (Wp <= 64) wsync(); else sync();
     } else {
@@ -328,7 +342,7 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
 #if defined(DCTFHE_ABLATE_EXCH)
         static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[u][(j + 1) % P]; });
 #else
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[u][j]; });
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::template ex<i + 1>(pass_addr<LOGM, P, i>(t, j))] = y[u][j]; });
 #endif
       });
 #else
@@ -343,7 +357,7 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
 #if defined(DCTFHE_ABLATE_EXCH)   // timing experiments only: no LDS traffic, wrong results
         static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[(j + 1) % P]; });
 #else
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::template ex<i + 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
 #endif
         DCTFHE_FFT_SCHED_BARRIER();
       });
@@ -353,7 +367,7 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
         constexpr int u = decltype(U)::value;
         const cplx* ex = exch + u * G::EXCH_ELEMS;
 #if !defined(DCTFHE_ABLATE_EXCH)
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::skew(pass_addr<LOGM, P, i + 1>(t, j))]; });
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::template ex<i + 1>(pass_addr<LOGM, P, i + 1>(t, j))]; });
 #endif
       });
       DCTFHE_FFT_SCHED_BARRIER();
@@ -420,7 +434,7 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
 #if defined(DCTFHE_ABLATE_EXCH)
         static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = y[(j + 1) % P]; });
 #else
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::skew(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::template ex<i - 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
 #endif
       } else {
         static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = mul_root64<j*(64 / (4 * P)), -1>(y[j]); });
@@ -434,7 +448,7 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
         constexpr int u = decltype(U)::value;
         const cplx* ex = exch + u * G::EXCH_ELEMS;
 #if !defined(DCTFHE_ABLATE_EXCH)
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::skew(pass_addr<LOGM, P, i - 1>(t, j))]; });
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::template ex<i - 1>(pass_addr<LOGM, P, i - 1>(t, j))]; });
 #endif
       });
       if constexpr (Wp <= 64) wsync(); else sync();
