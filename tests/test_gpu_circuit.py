@@ -186,6 +186,25 @@ def test_input_on_a_key_prefix_and_tail_guard():
         sess = qm._session("execute", 3)
         with pytest.raises(_lib.DctfheError, match="beyond 512"):
             sess.upload(cts)
+        # the compact wire form (rows of dim mask words + body): the same guard on rows wider than the effective dimension, rows of
+        # exactly input_dim + 1 words accepted, and a row width the key does not have refused
+        wide = qm._keys.encrypt(qm.encode_input(q).reshape(-1), 640)
+        assert wide.shape[1] == 641 and not wide[:, 512:640].any()
+        sess.upload(wide, 640)
+        wide[7, 600] = 3
+        with pytest.raises(_lib.DctfheError, match="beyond 512"):
+            sess.upload(wide, 640)
+        sess.upload(qm._keys.encrypt(qm.encode_input(q).reshape(-1), 512), 512)
+        sess.run()
+        out_dim = sess.dims()[1]
+        got = qm.decode_output(qm._keys.decrypt(sess.download(out_dim).reshape(-1, out_dim + 1), out_dim).reshape(3, -1))
+        assert np.array_equal(got, _oracle_out(qm, q))
+        with pytest.raises(_lib.DctfheError, match="mask words"):
+            sess.upload(wide, qm._keys.D + 64)
+        with pytest.raises(_lib.DctfheError, match="mask words"):
+            qm._keys.encrypt(qm.encode_input(q).reshape(-1), 256)            # narrower than what these parameters mask
+        with pytest.raises(_lib.DctfheError, match="the output needs"):
+            sess.download(out_dim - 8)
     finally:
         qm.close()
 
