@@ -30,6 +30,9 @@
 #ifndef DCTFHE_SHARED_TWIDDLES
 #define DCTFHE_SHARED_TWIDDLES 1
 #endif
+#ifndef DCTFHE_PAIR_STAGGER
+#define DCTFHE_PAIR_STAGGER 0      // experiment switch (fft_forward_n): s_sleep units the younger half of a 512-thread workgroup waits; OFF
+#endif
 
 // pinning the interleaved order with scheduling barriers measured 8% slower than leaving hipcc free (N = 8192)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PIN_FFT_ORDER)
@@ -363,6 +366,14 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
       });
 #endif
       if constexpr (W <= 64) wsync(); else sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+      // Experiment, off: the two waves of a SIMD (w and w + 4 of a 512-thread workgroup) leave this barrier together and gather, compute
+      // and scatter in the same phase; holding the younger half back by 64-512 cycles de-phases them for the barrier-free stretch that
+      // follows: -0.5 % at N = 8192, -1.6 % at N = 4096 (profiles/r03_exp_stagger.log).  NOT shipped: the same one-line branch in the
+      // single-transform path made hipcc demote that kernel's register arrays to scratch (170 -> 2 716 ms per launch, same log) -- a
+      // third of a per cent is not worth standing that close to the cliff.
+      if constexpr (W > 64 && DCTFHE_PAIR_STAGGER > 0) { if (threadIdx.x & 256) __builtin_amdgcn_s_sleep(DCTFHE_PAIR_STAGGER); }
+#endif
       static_for<0, NP>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const cplx* ex = exch + u * G::EXCH_ELEMS;

@@ -39,3 +39,21 @@ def test_no_gpu_fails_loudly():
     from dctfhe.engine import Context
     with pytest.raises(DctfheError, match="no CPU path"):
         Context(0)
+
+
+def test_build_recorded_kernel_resources():
+    """__graft_entry__.build() records registers / scratch / occupancy of every kernel it compiles and refuses a library whose bootstrap
+    kernels fell off the register cliff (hipcc has demoted their register arrays to scratch over one-line edits: DESIGN.md section 5).
+    Here: the record of the library in the tree, when this checkout built it."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dct-cryptonets_amd", "build_resources.txt")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("library not built by this checkout's build() (no record)")
+    rows = [l.split() for l in open(path) if l.strip() and not l.startswith("#")]
+    pbs = [r for r in rows if "pbs_kernel" in r[0]]
+    assert len(pbs) >= 20
+    for name, vgpr, agpr, scratch, occ in pbs:
+        p16 = re.search(r"pbs_kernelILi\d+ELi\d+ELi\d+ELi16E", name) is not None
+        assert int(scratch) <= 128 and (int(occ) >= 2 or p16), (name, vgpr, scratch, occ)
