@@ -179,6 +179,13 @@ def plan_passes(req_warm, req_steps, warm_done, steps_done, pass_s, remaining_s)
     return warm_done + more_warm, steps_done + more_steps
 
 
+def first_pass_is_the_step(first_s, remaining_s, req_warm, req_steps, interrupted=False):
+    """The first pass is bracketed and timed like a step.  It IS the timed step when nothing else was asked for (--warmup 0 --steps 1),
+    when the run was interrupted, or when what is left of the budget does not hold another pass with 15 % to spare -- a multi-image
+    config whose one pass takes minutes then ends inside the driver's wall instead of running a warm-up and a timed pass back to back."""
+    return bool(interrupted or (req_warm == 0 and req_steps <= 1) or remaining_s < 1.15 * first_s)
+
+
 def self_launch(args_list, n, module="torch.distributed.run"):
     """`python bench.py --gpus N` outside torch.distributed.run: start N ranks as CHILD processes (never an exec of a
     process that has touched the GPU -- nothing here has) and hand back their exit code."""
@@ -346,10 +353,10 @@ def main():
     sync()
     first_s = max_over_ranks(time.time() - t_first, world, cdev)
     state.update(passes=1, last_s=first_s)
-    can_continue = all_true(remaining() >= 1.15 * first_s and not interrupted["flag"], world, cdev)
     timings = []
     warm_done, steps_done = 0, 0
-    first_pass_counted = not can_continue or (args.warmup == 0 and args.steps <= 1)
+    # every rank takes the same branch: the first pass counts as soon as ONE rank says so
+    first_pass_counted = not all_true(not first_pass_is_the_step(first_s, remaining(), args.warmup, args.steps, interrupted["flag"]), world, cdev)
     if first_pass_counted:
         timings.append(first_timing)
         steps_done, elapsed = 1, first_s

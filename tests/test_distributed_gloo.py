@@ -117,3 +117,17 @@ def test_bench_budget_plan():
     assert bench.plan_passes(2, 7, 1, 0, 15.0, float("inf")) == (2, 7) and bench.plan_passes(0, 1, 0, 1, 60.0, float("inf")) == (0, 1)
     # --warmup 0: planned from the first timed step
     assert bench.plan_passes(0, 20, 0, 1, 15.0, 100.0) == (0, 7)
+
+
+def test_bench_first_pass_rule():
+    """the first, bracketed pass becomes the timed step exactly when another pass does not fit (config #4 with 8 images per
+    GPU takes ~5 minutes per pass; a warm-up pass plus a timed pass blew the driver's 600 s)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert not bench.first_pass_is_the_step(12.3, 370.0, 5, 20)              # headline config: 25 more passes fit
+    assert bench.first_pass_is_the_step(285.0, 65.0, 5, 20)                  # r18_3_32 x 8 images: nothing else fits
+    assert bench.first_pass_is_the_step(100.0, 110.0, 1, 3)                  # one more pass would fit only without the 15 % margin
+    assert not bench.first_pass_is_the_step(100.0, 116.0, 1, 3)
+    assert bench.first_pass_is_the_step(1.0, 1e9, 0, 1)                      # --warmup 0 --steps 1: that pass is what was asked for
+    assert bench.first_pass_is_the_step(1.0, 1e9, 5, 20, interrupted=True)
+    assert not bench.first_pass_is_the_step(50.0, float("inf"), 0, 3)        # --budget-s 0

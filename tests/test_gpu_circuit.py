@@ -200,7 +200,7 @@ def test_input_on_a_key_prefix_and_tail_guard():
         got = qm.decode_output(qm._keys.decrypt(sess.download(out_dim).reshape(-1, out_dim + 1), out_dim).reshape(3, -1))
         assert np.array_equal(got, _oracle_out(qm, q))
         with pytest.raises(_lib.DctfheError, match="mask words"):
-            sess.upload(wide, qm._keys.D + 64)
+            sess.upload(np.zeros((wide.shape[0], qm._keys.D + 65), np.uint64), qm._keys.D + 64)
         with pytest.raises(_lib.DctfheError, match="mask words"):
             qm._keys.encrypt(qm.encode_input(q).reshape(-1), 256)            # narrower than what these parameters mask
         with pytest.raises(_lib.DctfheError, match="the output needs"):
