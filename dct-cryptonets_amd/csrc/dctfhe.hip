@@ -68,8 +68,9 @@ struct TierKeys {
   uint64_t* d_ksk = nullptr;     // [D][lk][n+1]
   uint64_t* d_colsum = nullptr;  // [n+1], over all D*lk rows
   std::map<int, uint64_t*>* colsum_eff = nullptr;   // column sums over the first Deff*lk rows (shared with the key's owner)
-  int8_t* d_kskT = nullptr;      // signed byte limbs, [8(n+1) padded to 128][D*lk], for the MFMA key switch
+  int8_t* d_kskT = nullptr;      // signed byte limbs, [limbs(n+1) padded to 128][D*lk], for the MFMA key switch
   int ncol_pad = 0;
+  int limbs = 8;                 // byte limbs kept per key word (ks_limbs): the key lives on the 2^-(8 limbs) torus grid
   bool own_ksk = false;
   cplx* d_bsk = nullptr;         // [n][rows][k+1][P][T]; unroll 2: [3n/2 blocks] for the pair secret
   cplx* d_wtab = nullptr;        // unroll 2: e^{i pi m/N}, m < 2N, then e^{2 pi i k/8}, k < 8
@@ -530,6 +531,15 @@ static int gen_bsk_std_chunk(dctfhe_client_key* C, int tier, int i0, int ni, uin
   return 0;
 }
 
+// Precision of a key-switch key: the torus grid its words live on, 2^-(8 limbs).  The finest gadget level sits at 2^-(lk betak) and the
+// row noise (sigma_lwe >= 2^-19 on every shipped tier) at least 6 bits above the grid: limbs >= (lk betak + 6) / 8, as a power of two
+// (the matrix-core epilogue folds a word's limbs with lane shuffles).  Table tiers (9 levels of base 4): 4 limbs; one-bit tiers (5
+// levels): 2 limbs -- a half and a quarter of round 2's GEMM.
+static int ks_limbs(const dctfhe_tier& t) {
+  const int bits = t.lk * t.betak + 6;
+  return bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+}
+
 // ---- evaluation keys ------------------------------------------------------------------------------
 static size_t tier_bsk_blocks(const dctfhe_tier& t) { return (size_t)(t.unroll == 2 ? 3 * t.n / 2 : t.n); }
 static size_t tier_bsk_elems(const dctfhe_tier& t) {   // complex values of the Fourier key, without the warm-up padding
@@ -552,9 +562,10 @@ static int eval_alloc(dctfhe_ctx* ctx, const dctfhe_params* params, std::unique_
     tk.t = t;
     if (t.ksk_share >= 0) {
       const TierKeys& o = E->tiers[t.ksk_share];
-      tk.d_ksk = o.d_ksk; tk.d_colsum = o.d_colsum; tk.d_kskT = o.d_kskT; tk.ncol_pad = o.ncol_pad; tk.colsum_eff = o.colsum_eff;
+      tk.d_ksk = o.d_ksk; tk.d_colsum = o.d_colsum; tk.d_kskT = o.d_kskT; tk.ncol_pad = o.ncol_pad; tk.colsum_eff = o.colsum_eff; tk.limbs = o.limbs;
     } else {
       tk.own_ksk = true;
+      tk.limbs = ks_limbs(t);
       tk.colsum_eff = new std::map<int, uint64_t*>();
       const size_t rows = (size_t)D * t.lk;
       HIPCHK(hipMalloc(&tk.d_ksk, rows * (t.n + 1) * 8));
@@ -562,7 +573,7 @@ static int eval_alloc(dctfhe_ctx* ctx, const dctfhe_params* params, std::unique_
       // the i8 MFMA key switch reads digits as SIGNED bytes: offset digits in [0, 2^betak) need betak <= 7;
       // wider gadgets and shapes the tiling does not cover go to the integer-VALU GEMM
       if (rows % 64 == 0 && rows <= (1u << 17) && t.betak <= 7) {
-        tk.ncol_pad = ((8 * (t.n + 1) + 127) / 128) * 128;
+        tk.ncol_pad = ((tk.limbs * (t.n + 1) + 127) / 128) * 128;
         HIPCHK(hipMalloc(&tk.d_kskT, (size_t)tk.ncol_pad * rows));
       }
     }
@@ -605,7 +616,18 @@ static int eval_finish(dctfhe_eval_keys* E) {
     if (!tk.own_ksk) continue;
     const size_t rows = (size_t)E->p.D * t.lk;
     hipLaunchKernelGGL(k_ksk_colsum, dim3((t.n + 256) / 256), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.d_colsum);
-    if (tk.d_kskT) hipLaunchKernelGGL(k_ksk_to_limbs, dim3(4096), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.ncol_pad, tk.d_kskT);
+    if (tk.d_kskT) {
+      // the limb form keeps the top tk.limbs bytes of every word: make sure nothing sits below them (an imported key must be on the grid)
+      DevBuf flag;
+      HIPCHK(flag.alloc(sizeof(int)));
+      HIPCHK(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_ksk_off_grid, dim3(2048), dim3(256), 0, st, tk.d_ksk, rows * (size_t)(t.n + 1), tk.limbs, flag.as<int>());
+      int bad = 0;
+      HIPCHK(hipMemcpyAsync(&bad, flag.p, sizeof bad, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (bad) return fail("tier %d: key-switch key words off the 2^-%d torus grid (a key made by another build?)", ti, 8 * tk.limbs);
+      hipLaunchKernelGGL(k_ksk_to_limbs, dim3(4096), dim3(256), 0, st, tk.d_ksk, (int)rows, t.n, tk.limbs, tk.ncol_pad, tk.d_kskT);
+    }
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -622,7 +644,7 @@ extern "C" int dctfhe_eval_keys_generate(dctfhe_client_key* C, dctfhe_eval_keys*
     const dctfhe_tier& t = C->p.tiers[ti];
     TierKeys& tk = E->tiers[ti];
     if (tk.own_ksk) {
-      hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)((size_t)D * t.lk)), dim3(256), 0, st, C->d_S, C->d_s, t.n, t.lk, t.betak, t.lwe_sigma, C->pub, C->sec,
+      hipLaunchKernelGGL(k_ksk_gen, dim3((unsigned)((size_t)D * t.lk)), dim3(256), 0, st, C->d_S, C->d_s, t.n, t.lk, t.betak, ks_limbs(t), t.lwe_sigma, C->pub, C->sec,
                          (uint64_t)(STREAM_KSK + 2 * ti), tk.d_ksk);
       HIPCHK(hipGetLastError());
     }
@@ -657,7 +679,8 @@ extern "C" int dctfhe_eval_keys_destroy(dctfhe_eval_keys* E) { delete E; return 
 
 // ---- evaluation-key persistence: header + params, then per tier its own key-switch key (u64) and its Fourier bootstrap key
 // version 2: the Fourier bootstrap keys carry 2^-64 / M (accumulator updates in units of the whole torus, fft_core.h); version 1 carried 1 / M
-static constexpr uint32_t EVAL_BLOB_VERSION = 2;
+// version 3: the key-switch keys live on the 2^-(8 ks_limbs) torus grid (version-2 keys used all 64 bits and would lose their low bytes)
+static constexpr uint32_t EVAL_BLOB_VERSION = 3;
 struct EvalBlobHeader { uint32_t magic, version; uint64_t total_bytes; dctfhe_params params; };
 static size_t eval_blob_size(const dctfhe_params& p) {
   size_t n = sizeof(EvalBlobHeader);
@@ -881,8 +904,11 @@ static int dev_keyswitch(dctfhe_keys* K, int tier, const uint64_t* d_cts, size_t
   hipLaunchKernelGGL(k_ks_decompose, dim3(grid), dim3(256), 0, st, d_cts, count, L, De, shift, body_add, t.lk, t.betak, d_digits, d_bodies);
   if (tk.d_kskT) {   // matrix-core path: i8 digits x signed byte limbs of the key
     const unsigned ncb = (unsigned)(tk.ncol_pad / 128), nrb = (unsigned)((count + 127) / 128), cpx = (ncb + 7) / 8;
-    hipLaunchKernelGGL(k_ks_mfma, dim3(8 * cpx * nrb), dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, tk.ncol_pad, colsum, t.n,
-                       t.betak, d_small);
+#define KS_LAUNCH(LB)                                                                                                                      \
+    hipLaunchKernelGGL(k_ks_mfma<LB>, dim3(8 * cpx * nrb), dim3(256), 0, st, d_digits, d_bodies, count, De * t.lk, tk.d_kskT, D * t.lk, tk.ncol_pad, \
+                       colsum, t.n, t.betak, d_small)
+    if (tk.limbs == 2) KS_LAUNCH(2); else if (tk.limbs == 4) KS_LAUNCH(4); else KS_LAUNCH(8);
+#undef KS_LAUNCH
   } else {           // shapes the MFMA tiling does not cover (D*lk not a multiple of 64, betak = 8): integer VALU GEMM
     constexpr int CT = 16;
     dim3 g2((t.n + 1 + 255) / 256, (unsigned)((count + CT - 1) / CT));

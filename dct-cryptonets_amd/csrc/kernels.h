@@ -111,15 +111,21 @@ __global__ void k_lwe_phase(const uint8_t* __restrict__ S, int dim, const uint64
 
 // ------------------------------------------------------------------------------------------ keygen
 // key-switch key: one block per row (i, lev): LWE_s(S_i * 2^(64 - betak (lev+1)))
-__global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restrict__ s, int n, int lk, int betak,
+// The key lives on a COARSE TORUS GRID of 2^-(8 limbs): its mask words are drawn on that grid and the body is rounded to it (a rounding
+// of 2^-(8 limbs) / sqrt(12), far below the row's noise sigma: dctfhe.hip ks_limbs() picks limbs >= (lk betak + 6) / 8).  A key-switch
+// output only ever meets a mod switch to 2N <= 2^14 levels under a noise of 2^-5 .. 2^-11: the low 32-48 bits of a 64-bit key word
+// carried nothing, and the matrix-core GEMM spent half to three quarters of its work multiplying them (round 2: 8 byte limbs per word).
+__global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restrict__ s, int n, int lk, int betak, int limbs,
                           double sigma, rng_key pub, rng_key sec, uint64_t stream, uint64_t* __restrict__ ksk) {
   __shared__ uint64_t red[16];
   const size_t row = blockIdx.x;
   const int i = (int)(row / lk), lev = (int)(row % lk);
   uint64_t* dst = ksk + row * (size_t)(n + 1);
+  const int drop = 64 - 8 * limbs;                                   // low bits that are not stored (0 for limbs = 8)
+  const uint64_t mask = drop ? ~0ULL << drop : ~0ULL, half = drop ? 1ULL << (drop - 1) : 0;
   uint64_t part = 0;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    const uint64_t a = rnd64(pub, stream, row * (uint64_t)(n + 1) + j);
+    const uint64_t a = rnd64(pub, stream, row * (uint64_t)(n + 1) + j) & mask;
     dst[j] = a;
     if (s[j]) part += a;
   }
@@ -127,8 +133,15 @@ __global__ void k_ksk_gen(const uint8_t* __restrict__ S, const uint8_t* __restri
   if (threadIdx.x == 0) {
     uint64_t b = sum + (uint64_t)gauss_torus(sec, stream + 1, row, sigma);
     if (S[i]) b += 1ULL << (64 - betak * (lev + 1));
-    dst[n] = b;
+    dst[n] = (b + half) & mask;
   }
+}
+// any key word off the 2^-(8 limbs) grid?  (an imported key must be what k_ksk_gen makes: the limb form drops the low bytes unseen)
+__global__ void k_ksk_off_grid(const uint64_t* __restrict__ ksk, size_t words, int limbs, int* __restrict__ flag) {
+  const uint64_t low = limbs >= 8 ? 0 : ~(~0ULL << (64 - 8 * limbs));
+  int bad = 0;
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < words; x += (size_t)gridDim.x * blockDim.x) bad |= (ksk[x] & low) != 0;
+  if (bad) atomicOr(flag, 1);
 }
 
 // secret of the two-bit blind rotation: per pair (s1, s2) the three products s1(1-s2), (1-s1)s2, s1 s2
@@ -269,18 +282,20 @@ k_ks_gemm(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
 // (ksk = sum_k s_k 2^(8k), s_k in [-128,127], carries propagated), stored K-contiguous per output column:
 // kskT[(j*8 + k) * R + r].  Then C[c][j*8+k] = sum_r dig'[c][r] * s_k[r][j] is an i8 x i8 -> i32 GEMM for
 // v_mfma_i32_32x32x32_i8 (|C| <= R * 127 * 128 < 2^31 for R <= 2^17), and out = fix - sum_k C_k << 8k (mod 2^64).
-__global__ void k_ksk_to_limbs(const uint64_t* __restrict__ ksk, int R, int n, int ncol_pad /* 8*(n+1) rounded up */, int8_t* __restrict__ kskT) {
-  const size_t total = (size_t)R * (ncol_pad / 8);
+// Only the TOP `limbs` byte limbs of a key word are stored (the key sits on the 2^-(8 limbs) grid: the others are zero and carry nothing
+// up): column j*limbs + k' holds limb 8 - limbs + k'.
+__global__ void k_ksk_to_limbs(const uint64_t* __restrict__ ksk, int R, int n, int limbs, int ncol_pad /* limbs*(n+1) rounded up */, int8_t* __restrict__ kskT) {
+  const size_t total = (size_t)R * (ncol_pad / limbs);
   for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (size_t)gridDim.x * blockDim.x) {
     const size_t r = x % R;
     const size_t j = x / R;
     uint64_t v = (j <= (size_t)n) ? ksk[r * (size_t)(n + 1) + j] : 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
+    v >>= 64 - 8 * limbs;                                              // (limbs = 8: a shift by 0)
+    for (int k = 0; k < limbs; k++) {
       int b = (int)(v & 0xFF);
       v >>= 8;
       if (b >= 128) { b -= 256; v += 1; }
-      kskT[(j * 8 + k) * (size_t)R + r] = (int8_t)b;
+      kskT[(j * limbs + k) * (size_t)R + r] = (int8_t)b;
     }
   }
 }
@@ -291,6 +306,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // Block: 128 ciphertexts x 128 limb columns (16 output words), K step 64, 4 waves each owning a 64 x 64 quadrant
 // (2 x 2 MFMA tiles).  Both operands are K-contiguous, so a lane's 16-byte fragment is one ds_read_b128 and
 // the A and B fragments of a lane cover the same 16 k's whatever order the hardware walks them in.
+template <int LIMBS>        // byte limbs stored per key word: 2, 4 or 8 (the top ones)
 __global__ void __launch_bounds__(256)
 k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodies, size_t count, int R /* rows used: Deff*lk */,
           const int8_t* __restrict__ kskT, int ldk /* row stride of kskT: D*lk */, int ncol_pad, const uint64_t* __restrict__ colsum /* over the R rows used */,
@@ -368,19 +384,20 @@ k_ks_mfma(const uint8_t* __restrict__ digits, const uint64_t* __restrict__ bodie
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
   }
-  // epilogue: C tile layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); limb k = col & 7
-  const int limb = lane & 7;
+  // epilogue: C tile layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); limb k' = col % LIMBS stands for 2^(8 (8 - LIMBS + k'))
+  static_assert(LIMBS == 2 || LIMBS == 4 || LIMBS == 8, "limb groups are folded with lane shuffles");
+  const int limb = lane & (LIMBS - 1);
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-      const size_t word = (col0 + wn * 64 + b * 32 + (lane & 31)) >> 3;     // output word j of this lane's column
+      const size_t word = (col0 + wn * 64 + b * 32 + (lane & 31)) / LIMBS;     // output word j of this lane's column
 #pragma unroll
       for (int e = 0; e < 16; e++) {
-        uint64_t v = (uint64_t)(int64_t)acc[a][b][e] << (8 * limb);
+        uint64_t v = (uint64_t)(int64_t)acc[a][b][e] << (8 * (8 - LIMBS + limb));
         v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
+        if constexpr (LIMBS >= 4) v += __shfl_xor(v, 2);
+        if constexpr (LIMBS >= 8) v += __shfl_xor(v, 4);
         const size_t c = c0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (limb == 0 && c < count && word <= (size_t)n) {
           const uint64_t fix = ((uint64_t)1 << (betak - 1)) * colsum[word] + (word == (size_t)n ? bodies[c] : 0);

@@ -84,9 +84,16 @@ class ParamSet:
 
 
 # ------------------------------------------------------------------------------------------ variances
+def ks_limbs(t):
+    """byte limbs kept per key-switch-key word (csrc/dctfhe.hip ks_limbs): the key lives on the 2^-(8 limbs) torus grid"""
+    bits = t.lk * t.betak + 6
+    return 2 if bits <= 16 else 4 if bits <= 32 else 8
+
+
 def var_keyswitch(D_eff, t):
     B = 2.0 ** t.betak
-    return D_eff * t.lk * ((B * B + 2) / 12.0) * t.lwe_sigma ** 2 + (D_eff / 2.0) * 2.0 ** (-2 * t.betak * t.lk) / 12.0
+    row = t.lwe_sigma ** 2 + 2.0 ** (-16 * ks_limbs(t)) / 12.0          # the key's body is rounded to its grid: 2^-32 (2^-16 on the one-bit tiers)
+    return D_eff * t.lk * ((B * B + 2) / 12.0) * row + (D_eff / 2.0) * 2.0 ** (-2 * t.betak * t.lk) / 12.0
 
 
 def var_modswitch(t, centred=True):

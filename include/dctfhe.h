@@ -118,7 +118,9 @@ int dctfhe_eval_keys_import(dctfhe_ctx* ctx, const void* buf, size_t size, dctfh
 /* test / client views */
 int dctfhe_client_key_export_secret(dctfhe_client_key* client, uint8_t* big_key /* D */, uint8_t* small_key /* n_max */);
 /* standard-domain keys: ksk [D][lk][n+1] (public, from the evaluation keys); bsk [n][(k+1)l][k+1][N], regenerated from the
- * client's streams -- exactly what dctfhe_eval_keys_generate transformed to the Fourier domain */
+ * client's streams -- exactly what dctfhe_eval_keys_generate transformed to the Fourier domain.
+ * Key-switch-key words live on the torus grid 2^-(8 limbs), limbs = 2 / 4 / 8 for lk*betak + 6 <= 16 / <= 32 / more (their low
+ * 64 - 8 limbs bits are zero: masks drawn on the grid, bodies rounded to it); dctfhe_eval_keys_import refuses a key off that grid. */
 int dctfhe_eval_keys_export_ksk(dctfhe_eval_keys* eval, int tier, uint64_t* out);
 int dctfhe_client_key_export_bsk(dctfhe_client_key* client, int tier, uint64_t* out);
 /* the generator itself: `count` 64-bit outputs (key, stream, idx0 + i).  _host runs on the CPU (known-answer tests need no GPU) */

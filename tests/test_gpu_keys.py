@@ -108,6 +108,46 @@ def test_server_evaluates_with_imported_evaluation_keys():
         bad[0] ^= 0xFF
         with pytest.raises(DctfheError, match="magic"):
             server.load_evaluation_keys(bad)
+        # a key-switch key off its torus grid (the matrix-core form keeps the top ks_limbs bytes of a word only) is refused too
+        from dctfhe import _lib
+        off = blob.copy()
+        off[16 + C.sizeof(_lib.Params)] ^= 1                      # lowest bit of the first key-switch-key word of tier 0
+        with pytest.raises(DctfheError, match="torus grid"):
+            server.load_evaluation_keys(off)
+        server.load_evaluation_keys(blob)                         # (and the good blob still loads afterwards)
     finally:
         server.close()
         client.close()
+
+
+def test_key_switch_keys_live_on_their_torus_grid(gpu_ctx, oracle):
+    """the key-switch key of a tier keeps ks_limbs = 2 (one-bit tiers: 5 levels of base 4) or 4 (table tiers: 9 levels) top bytes per
+    word -- masks drawn on that grid, body rounded to it -- so that the i8 matrix-core GEMM multiplies 2 / 4 byte limbs per word instead
+    of 8.  The exported key IS that key (low bytes zero), each row still an encryption of S_i / B^(lev+1) under the small key with
+    the tier's noise, and the device key switch equals the oracle's on it bit for bit."""
+    from dctfhe import params as P
+    from dctfhe.engine import Keys
+    ps = P.default_params()
+    keys = Keys(gpu_ctx, P.to_c_params(ps), seed=11)
+    try:
+        S, s = keys.export_secret()
+        rng = np.random.default_rng(4)
+        cts = keys.encrypt(rng.integers(0, 16, 64).astype(np.uint64) << np.uint64(59))
+        seen = set()
+        for ti, t in enumerate(ps.tiers):
+            limbs = P.ks_limbs(t)
+            seen.add(limbs)
+            ksk = keys.export_ksk(ti)
+            low = np.uint64((1 << (64 - 8 * limbs)) - 1)
+            assert not (ksk & low).any() and (ksk & (low + np.uint64(1))).any(), t.name        # on the grid, and the grid's last bit is used
+            rows = ksk[:256].reshape(-1, t.n + 1)                                               # the first 256 key bits, every level
+            ph = oracle.lwe_phase(s[:t.n].copy(), t.n, rows).reshape(256, t.lk)
+            for lev in range(t.lk):
+                want = S[:256].astype(np.uint64) << np.uint64(64 - t.betak * (lev + 1))
+                err = (ph[:, lev] - want).astype(np.int64).astype(np.float64) / 2.0 ** 64
+                assert np.abs(err).max() < 6 * t.lwe_sigma + 2.0 ** (-8 * limbs), (t.name, lev)
+            small = keys.keyswitch(ti, cts)
+            assert np.array_equal(small, oracle.keyswitch(cts, ksk, t.betak)), t.name
+        assert seen == {2, 4}
+    finally:
+        keys.close()
