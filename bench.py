@@ -43,6 +43,9 @@ FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not 
 VALU_PER_ITERATION = {(13, 1, 1, 2): (2433, 8), (12, 1, 1, 2): (2365, 4), (11, 1, 1, 2): (2325, 2), (11, 1, 3, 1): (4511, 2), (11, 1, 3, 2): (6171, 2), (10, 2, 1, 1): (2792, 1),
                       (10, 2, 1, 2): (3802, 1), (10, 2, 2, 1): (4745, 1)}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4          # wave-instructions per second: 256 CUs x 4 SIMDs, one f64 wave instruction per 4 cycles, 2.4 GHz
+N_CU, SPEC_CLOCK_HZ = 256, 2.4e9
+L1_DELIVERY_BYTES_PER_CLK_CU = 64.0            # a CU's vector L1 returns one 64-byte half line per clock to the registers (a wave's 16 B/lane load: 16 clocks);
+                                               # measured here: 60 B/clk in the key phases of the three-level kernel (profiles/r03_exp_phase_clock.log)
 
 
 def _dct_batch(n, seed):
@@ -508,6 +511,17 @@ def main():
             res["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": instr / avg_launch_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
                                           "frac": instr / avg_launch_s / VALU_ISSUE_PEAK, "valu_instr_per_iteration_per_wave": vi[0], "waves_per_ciphertext": vi[1],
                                           "note": "instruction counts from the ISA of the shipped build; peak at the 2.4 GHz spec clock (the kernels hold 2.04-2.38 GHz)"}
+        # The other roof, found with the phase clock of tools/exp_pbs.hip (profiles/r03_exp_phase_clock.log): every ciphertext pulls the whole
+        # Fourier key through its CU's vector L1 once -- bsk_bytes per ciphertext, never reused inside the CU -- and a CU's L1 hands 64 bytes
+        # per clock to its registers.  The key-product phases of a bootstrap run AT that rate and the transform phases at the f64 issue rate,
+        # one after the other for the waves of a workgroup that share its barriers: the two fractions add up to the time.
+        l1_peak = L1_DELIVERY_BYTES_PER_CLK_CU * N_CU * SPEC_CLOCK_HZ
+        l1_bytes = bsk_bytes * cts_per_launch
+        res["roofline_l1_delivery"] = {"bound": "vector_l1_to_registers", "achieved": l1_bytes / avg_launch_s / 1e12, "peak": l1_peak / 1e12, "unit": "TB/s",
+                                       "frac": l1_bytes / avg_launch_s / l1_peak, "bytes_per_bootstrap": bsk_bytes,
+                                       "note": "64 B/clk/CU x 256 CUs at the 2.4 GHz spec clock; key bytes per bootstrap x bootstraps per launch / the same measured launch duration. "
+                                               "frac + roofline_valu_issue.frac ~ 0.9-1: the key phases (L1-bound) and the transform phases (issue-bound) of the "
+                                               "lock-step waves of a CU do not overlap (DESIGN.md section 5)"}
         if cpu_box.get("res") is not None:
             res["cpu_baseline"] = cpu_box["res"]
             if "value" in res["cpu_baseline"]:

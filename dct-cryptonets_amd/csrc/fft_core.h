@@ -34,6 +34,16 @@
 #define DCTFHE_PAIR_STAGGER 0      // experiment switch (fft_forward_n): s_sleep units the younger half of a 512-thread workgroup waits; OFF
 #endif
 
+// Wave-local passes of the NP-polynomial transforms, polynomial by polynomial: {butterflies; scatter; gather} of polynomial u, then of
+// u + 1 -- the LDS unit moves polynomial u while the VALU runs the butterflies of u + 1 (each with a twiddle chain of its own).
+#ifndef DCTFHE_PIPE_LOCAL
+#define DCTFHE_PIPE_LOCAL 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PIPE_PIN)
+#define DCTFHE_PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DCTFHE_PIPE_SCHED_BARRIER() ((void)0)
+#endif
 // pinning the interleaved order with scheduling barriers measured 8% slower than leaving hipcc free (N = 8192)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PIN_FFT_ORDER)
 #define DCTFHE_FFT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -44,6 +54,18 @@
 namespace dctfhe {
 
 struct cplx { double re, im; };
+
+// Phase clock for timing experiments (tools/exp_pbs.hip, -DDCTFHE_PHASE_TIMERS): at<K>() charges the shader-clock ticks since the last
+// call to phase K.  Scalar registers only; reading the clock drains the wave's LDS queue (s_memtime returns through lgkmcnt), so a
+// phase includes the completion of the LDS operations issued in it.  no_tick: the shipped kernels.
+struct no_tick { template <int K> HD void at() {} };
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PHASE_TIMERS)
+struct phase_clock {
+  unsigned long long last, acc[12];
+  __device__ __forceinline__ void start() { for (int k = 0; k < 12; k++) acc[k] = 0; last = __builtin_amdgcn_s_memtime(); }
+  template <int K> __device__ __forceinline__ void at() { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[K] += now - last; last = now; }
+};
+#endif
 
 HD cplx cmk(double re, double im) { cplx c; c.re = re; c.im = im; return c; }
 HD cplx cadd(cplx a, cplx b) { return cmk(a.re + b.re, a.im + b.im); }
@@ -306,8 +328,8 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch
 // while the gather of u+1 is still in flight (the LDS queue of a wave returns in order, so the compiler can wait
 // on a partial count).  One barrier pair per pass serves all NP polynomials.  Same arithmetic per polynomial,
 // in the same order, as fft_forward / fft_inverse: results are bit-identical to NP separate calls.
-template <int LOGM, int P, int NP, class Sync, class WSync>
-HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync) {
+template <int LOGM, int P, int NP, class Sync, class WSync, class Tick = no_tick>
+HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync, Tick&& tick = Tick{}) {
 #if defined(DCTFHE_ABLATE_FFT)
   return;
 #endif
@@ -317,14 +339,39 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
     constexpr int u = decltype(U)::value;
     static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = mul_root64<j*(64 / (4 * P)), +1>(v[u][j]); });
   });
+  [[maybe_unused]] cplx bpre = cmk(1.0, 0.0);      // DCTFHE_PIPE_LOCAL: the next pass's twiddle base, read a pass ahead
   static_for<0, S>([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int R = G::radix(i);
     constexpr int W = G::weight(i);
-    if constexpr (i < S - 1) {
+    if constexpr (i < S - 1 && W <= 64 && DCTFHE_PIPE_LOCAL) {
+      // this pass's twiddle base was read one pass ahead (bpre) wherever a pass precedes this one: a read issued here would sit BEHIND the
+      // previous pass's last gather in the wave's in-order LDS queue, and the first polynomial's butterflies would wait for all of it
+      cplx b;
+      if constexpr (i > 0) b = bpre; else b = tw[G::tw_offset(i) + (t % W)];
+      const cplx run0 = (i == 0) ? twist : cmk(1.0, 0.0);
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        cplx y[P];
+        small_dft<P, 1, -1>::run(v[u], y);
+        cplx run = run0;
+        if constexpr (i == 0) y[0] = cmul(y[0], run);
+        static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); y[k] = cmul(y[k], run); });
+        cplx* ex = exch + u * G::EXCH_ELEMS;
+        if constexpr (u == 0 && i + 1 < S - 1) bpre = tw[G::tw_offset(i + 1) + (t % G::weight(i + 1))];
+        wsync();
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::template ex<i + 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+        wsync();
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::template ex<i + 1>(pass_addr<LOGM, P, i + 1>(t, j))]; });
+        DCTFHE_PIPE_SCHED_BARRIER();
+      });
+    } else if constexpr (i < S - 1) {
       const cplx b = tw[G::tw_offset(i) + (t % W)];
       const cplx run0 = (i == 0) ? twist : cmk(1.0, 0.0);
+      if constexpr (DCTFHE_PIPE_LOCAL && i + 1 < S - 1) bpre = tw[G::tw_offset(i + 1) + (t % G::weight(i + 1))];
+      if constexpr (W > 64) tick.template at<0>();        // phase 0: accumulator update, decomposition
       if constexpr (W <= 64) wsync(); else sync();      // nobody still gathers from the buffers about to be written
+      if constexpr (W > 64) tick.template at<1>();        // phase 1: waiting at the leading barrier
 #if DCTFHE_SHARED_TWIDDLES
       // butterflies of all NP polynomials, then ONE running twiddle product applied to all of them (the chain costs
       // as much as applying it: 4 f64 instructions per step), then the scatters
@@ -365,7 +412,9 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
         DCTFHE_FFT_SCHED_BARRIER();
       });
 #endif
+      if constexpr (W > 64) tick.template at<2>();        // phase 2: butterflies + twiddles + scatter of the cross-wave pass
       if constexpr (W <= 64) wsync(); else sync();
+      if constexpr (W > 64) tick.template at<3>();        // phase 3: waiting at the barrier before the gather
 #if defined(__HIP_DEVICE_COMPILE__)
       // Experiment, off: the two waves of a SIMD (w and w + 4 of a 512-thread workgroup) leave this barrier together and gather, compute
       // and scatter in the same phase; holding the younger half back by 64-512 cycles de-phases them for the barrier-free stretch that
@@ -396,23 +445,51 @@ HD void fft_forward_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
       });
     }
   });
+  tick.template at<4>();                                  // phase 4: gather of the cross-wave pass, the wave-local passes
 }
 
-template <int LOGM, int P, int NP, class Sync, class WSync>
-HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync) {
+template <int LOGM, int P, int NP, class Sync, class WSync, class Tick = no_tick>
+HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist, cplx* exch, Sync&& sync, WSync&& wsync, Tick&& tick = Tick{}) {
 #if defined(DCTFHE_ABLATE_FFT)
   return;
 #endif
   using G = fft_geom<LOGM, P>;
   constexpr int S = G::S;
+  [[maybe_unused]] cplx bpre = cmk(1.0, 0.0);      // DCTFHE_PIPE_LOCAL: the next pass's twiddle base, read a pass ahead (see fft_forward_n)
   static_for<0, S>([&](auto Irev) {
     constexpr int i = S - 1 - decltype(Irev)::value;
     constexpr int R = G::radix(i);
     constexpr int W = G::weight(i);
+    if constexpr (i > 0 && G::weight(i > 0 ? i - 1 : 0) > 64) tick.template at<6>();             // phase 6: the passes that end in wave-local exchanges
+    constexpr bool PIPE = DCTFHE_PIPE_LOCAL && i > 0 && G::weight(i > 0 ? i - 1 : 0) <= 64;   // this pass ends in a wave-local exchange
+    constexpr bool PREV_PIPE = DCTFHE_PIPE_LOCAL && i < S - 1 && W <= 64;                      // ... and so did the one before it
     cplx b = cmk(1.0, 0.0), run0 = cmk(1.0, 0.0);
     if constexpr (i < S - 1) {
-      b = tw[G::tw_offset(i) + (t % W)];
+      if constexpr (PREV_PIPE) b = bpre; else b = tw[G::tw_offset(i) + (t % W)];
       if constexpr (i == 0) run0 = twist;
+    }
+    if constexpr (PIPE) {
+      static_for<0, NP>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr (i < S - 1) {
+          cplx run = run0;
+          static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); v[u][k] = cmulc(v[u][k], run); });
+        }
+        cplx y[P];
+        if constexpr (R == P) {
+          small_dft<P, 1, +1>::run(v[u], y);
+        } else {
+          static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v[u] + g * R, y + g * R); });
+        }
+        cplx* ex = exch + u * G::EXCH_ELEMS;
+        if constexpr (u == 0) bpre = tw[G::tw_offset(i - 1) + (t % G::weight(i - 1))];
+        wsync();
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; ex[G::template ex<i - 1>(pass_addr<LOGM, P, i>(t, j))] = y[j]; });
+        wsync();
+        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::template ex<i - 1>(pass_addr<LOGM, P, i - 1>(t, j))]; });
+        DCTFHE_PIPE_SCHED_BARRIER();
+      });
+      return;
     }
 #if DCTFHE_SHARED_TWIDDLES
     if constexpr (i < S - 1) {
@@ -454,7 +531,9 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
     });
     if constexpr (i > 0) {
       constexpr int Wp = G::weight(i - 1);
+      if constexpr (Wp > 64) tick.template at<7>();       // phase 7: twiddles + butterflies + scatter of the pass before the cross-wave gather
       if constexpr (Wp <= 64) wsync(); else sync();
+      if constexpr (Wp > 64) tick.template at<8>();       // phase 8: waiting at the barrier before the cross-wave gather
       static_for<0, NP>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const cplx* ex = exch + u * G::EXCH_ELEMS;
@@ -462,7 +541,9 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
         static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; v[u][j] = ex[G::template ex<i - 1>(pass_addr<LOGM, P, i - 1>(t, j))]; });
 #endif
       });
+      if constexpr (Wp > 64) tick.template at<9>();       // phase 9: the cross-wave gather
       if constexpr (Wp <= 64) wsync(); else sync();
+      if constexpr (Wp > 64) tick.template at<10>();      // phase 10: waiting at the trailing barrier
       DCTFHE_FFT_SCHED_BARRIER();
     }
   });

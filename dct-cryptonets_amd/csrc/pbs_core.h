@@ -194,6 +194,9 @@ HD cplx load_uniform_base(const cplx* base, unsigned lane) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PHASE_TIMERS) || defined(DCTFHE_PHASE_TIMERS) && defined(__HIPCC__)
+__device__ unsigned long long dctfhe_phase_ticks[16 * 12];      // timing experiments: ticks per phase of the waves of workgroup DCTFHE_PHASE_TIMERS
+#endif
 struct pbs_args {
   const uint64_t* ct_small;   // this ciphertext: n+1 words
   int n;
@@ -341,6 +344,12 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
     return A.zlut ? cmul(A.zlut[(1 << G::ZLO) + (m >> G::ZLO)], A.zlut[m & ((1u << G::ZLO) - 1)]) : A.wtab[m];
 #endif
   };
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PHASE_TIMERS)
+  phase_clock tick;
+  tick.start();
+#else
+  no_tick tick;
+#endif
   for (int i = 0; i < n; i += (MB ? 2 : 1)) {
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = make_uniform(A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT);
@@ -380,6 +389,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             else v[j] = cmk((double)(int16_t)(packed[j] >> (16 * (lev - 1))), (double)(int16_t)(packed[P + j] >> (16 * (lev - 1))));
           });
           fft_forward<G::LOGM, P>(v, t, tw, twist, exch, sync, wsync);
+          tick.template at<4>();                          // (general form) phase 4: decomposition + one forward transform
           cplx zb1 = cmk(1.0, 0.0), zb2 = cmk(1.0, 0.0);
           static_for<0, P>([&](auto J) {
             constexpr int j = decltype(J)::value;
@@ -434,6 +444,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
             });
             PBS_MBG_BAR_B();
           });
+          tick.template at<5>();                          // phase 5: the products with the key of one gadget row
         });
       });
     } else if constexpr (MB) {
@@ -449,7 +460,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
           if constexpr (r < P) v[p][r].re = (double)dg[0]; else v[p][r - P].im = (double)dg[0];
         });
       });
-      fft_forward_n<G::LOGM, P, 2>(v, t, tw, twist, exch, sync, wsync);
+      fft_forward_n<G::LOGM, P, 2>(v, t, tw, twist, exch, sync, wsync, tick);
       // zeta^{a} at this thread's points: one 16-byte gather per exponent and small transform from the 2N-entry root
       // table; inside a small transform the points are RL-th roots of unity apart, zeta_{j'} = zeta_0 * e^{-2 pi i a j'/RL}
       // -- a factor that only depends on a (the same for the whole ciphertext), read from the 8-entry table below.
@@ -638,7 +649,8 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
       pf_ptr += pf_step;
     }
 
-    if constexpr (G::PAIR) fft_inverse_n<G::LOGM, P, 2>(out, t, tw, twist, exch, sync, wsync);
+    tick.template at<5>();                                // phase 5: the products with the key (and the L2 warm-up touches)
+    if constexpr (G::PAIR) fft_inverse_n<G::LOGM, P, 2>(out, t, tw, twist, exch, sync, wsync, tick);
     static_for<0, K + 1>([&](auto Q) {
       constexpr int q = decltype(Q)::value;
       if constexpr (!G::PAIR) fft_inverse<G::LOGM, P>(out[q], t, tw, twist, exch, sync, wsync);
@@ -653,8 +665,14 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
         }
       });
     });
+    tick.template at<11>();                               // phase 11: (last pass of) the inverse transforms, accumulator update
   }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PHASE_TIMERS)
+  tick.template at<0>();
+  if (blockIdx.x == DCTFHE_PHASE_TIMERS && (threadIdx.x & 63) == 0)          // every wave of one workgroup reports: [wave][phase]
+    for (int k = 0; k < 12; k++) dctfhe_phase_ticks[(threadIdx.x >> 6) * 12 + k] = tick.acc[k];
+#endif
 #if defined(DCTFHE_DEVICE)
   if constexpr (KL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tiles fetched ahead of the last step (key padding) land before the wave ends
 #endif

@@ -51,6 +51,24 @@ void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   printf("mb=%d klds=%d pf=%d wrap=%d N=%5d k=%d l=%d P=%2d groups=%d threads=%4d lds=%6zu: %zu cts %.1f ms -> %.0f PBS/s, %.2f TFLOP/s\n", MB, KLDS, pf, wrap, N, K, L, P, GR, G::T * GR, lds, count, ms,
          count / (ms * 1e-3), fl * count / (ms * 1e-3) / 1e12);
   fflush(stdout);
+#if defined(DCTFHE_PHASE_TIMERS)
+  {
+    static const char* names[12] = {"acc update + decompose", "leading barrier (wait)", "fwd cross-wave pass: compute + scatter", "barrier before fwd gather (wait)",
+                                    "fwd gather + wave-local passes", "key products", "inv wave-local passes", "inv pass before cross-wave gather: compute + scatter",
+                                    "barrier before inv gather (wait)", "inv cross-wave gather", "trailing barrier (wait)", "inv last pass + accumulator update (general form: all inverse)"};
+    unsigned long long h[16 * 12];
+    CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(dctfhe_phase_ticks), sizeof h));
+    const int waves = G::T * GR / 64, iters = MB ? n / 2 : n;
+    for (int k = 0; k < 12; k++) {
+      printf("  phase %2d %-52s ticks/iteration per wave:", k, names[k]);
+      double sum = 0;
+      for (int w = 0; w < waves; w++) { printf(" %7.0f", (double)h[w * 12 + k] / iters); sum += (double)h[w * 12 + k] / iters; }
+      printf("   mean %7.0f\n", sum / waves);
+    }
+    double tot = 0; for (int k = 0; k < 12; k++) tot += (double)h[k] / iters;
+    printf("  total (wave 0) %.0f ticks/iteration\n", tot);
+  }
+#endif
   hipFree(d_wtab); hipFree(d_tw); hipFree(d_bsk); hipFree(d_small); hipFree(d_out); hipFree(d_dummy); hipFree(d_tab);
 }
 
