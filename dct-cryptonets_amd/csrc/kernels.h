@@ -478,6 +478,9 @@ pbs_kernel(pbs_launch a) {
     for (int x = threadIdx.x; x < G::ZLUT_ELEMS; x += blockDim.x) zl[x] = x < (1 << G::ZLO) ? a.wtab[x] : a.wtab[(size_t)(x - (1 << G::ZLO)) << G::ZLO];
   }
   __syncthreads();
+#if defined(DCTFHE_WAVE_STAGGER)   // experiment: the free-running waves of a workgroup (one ciphertext each) start DCTFHE_WAVE_STAGGER x ~4 100 clocks apart
+  if constexpr (T <= 64) { const int w0 = (threadIdx.x >> 6) + ((blockIdx.x >> 8) & 1) * GROUPS; for (int z = 0; z < w0 * DCTFHE_WAVE_STAGGER; z++) __builtin_amdgcn_s_sleep(64); }
+#endif
 #if defined(DCTFHE_STAGGER)   // experiment: desynchronise co-resident workgroups by half a transform
   if ((blockIdx.x >> 8) & 1) for (int z = 0; z < DCTFHE_STAGGER; z++) __builtin_amdgcn_s_sleep(64);
 #endif
