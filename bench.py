@@ -512,9 +512,10 @@ def main():
                                           "frac": instr / avg_launch_s / VALU_ISSUE_PEAK, "valu_instr_per_iteration_per_wave": vi[0], "waves_per_ciphertext": vi[1],
                                           "note": "instruction counts from the ISA of the shipped build; peak at the 2.4 GHz spec clock (the kernels hold 2.04-2.38 GHz)"}
         # The other roof, found with the phase clock of tools/exp_pbs.hip (profiles/r03_exp_phase_clock.log): every ciphertext pulls the whole
-        # Fourier key through its CU's vector L1 once -- bsk_bytes per ciphertext, never reused inside the CU -- and a CU's L1 hands 64 bytes
-        # per clock to its registers.  The key-product phases of a bootstrap run AT that rate and the transform phases at the f64 issue rate,
-        # one after the other for the waves of a workgroup that share its barriers: the two fractions add up to the time.
+        # Fourier key through its CU's vector L1 once -- bsk_bytes per ciphertext, never reused inside the CU -- and a CU's L1 hands at most
+        # 64 bytes per clock to its registers (42-51 measured: profiles/r03_exp_stream_l1_delivery.log).  The key-product phases of a bootstrap
+        # run at that ceiling and the transform phases at the f64 issue rate, one after the other for the waves of a workgroup that share
+        # its barriers: the two fractions add up to most of the time.
         l1_peak = L1_DELIVERY_BYTES_PER_CLK_CU * N_CU * SPEC_CLOCK_HZ
         l1_bytes = bsk_bytes * cts_per_launch
         res["roofline_l1_delivery"] = {"bound": "vector_l1_to_registers", "achieved": l1_bytes / avg_launch_s / 1e12, "peak": l1_peak / 1e12, "unit": "TB/s",

@@ -464,10 +464,9 @@ constexpr size_t pbs_lds_bytes(int groups) {
   return (size_t)G::TW_BYTES + (size_t)groups * G::GROUP_BYTES + (size_t)KLDS * 3 * (K + 1) * G::T * 16;
 }
 
-template <int LOGN, int K, int L, int P, int GROUPS, int MB = 0, int KLDS = 0, int XG = 0>
+template <int LOGN, int K, int L, int P, int GROUPS, int MB = 0, int KLDS = 0>
 __global__ void __launch_bounds__((pbs_geom<LOGN, K, L, P, MB>::T * GROUPS), ((P >= 16 || (pbs_geom<LOGN, K, L, P, MB>::T * GROUPS) >= 512) ? 1 : 2))
 pbs_kernel(pbs_launch a) {
-  static_assert(XG == 0 || (XG == GROUPS && KLDS == 0), "spectra change hands among ALL ciphertexts of a workgroup");
   using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int T = G::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -514,7 +513,6 @@ pbs_kernel(pbs_launch a) {
   A.kring = reinterpret_cast<const cplx*>(per_group + (size_t)GROUPS * G::GROUP_BYTES);
   A.kring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(per_group + (size_t)GROUPS * G::GROUP_BYTES);
   A.kwave = g;
-  A.cts_all = a.cts_small; A.e_first = (size_t)blockIdx.x * GROUPS; A.count_all = a.count;
 #if defined(DCTFHE_ABLATE_BARRIER)   // timing experiments only (tools/exp_pbs.hip): no workgroup barriers, wrong results
   if constexpr (true) {
 #else
@@ -522,10 +520,10 @@ pbs_kernel(pbs_launch a) {
 #endif
     // one ciphertext per wave (or less): every exchange and the rotation stage stay inside the wave, whose LDS
     // queue is in order -- no workgroup barrier anywhere in the loop, the waves of a workgroup run decoupled
-    pbs_thread<LOGN, K, L, P, MB, KLDS, GROUPS, XG>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P, MB, KLDS, GROUPS>(A, t, tw, stage, exch, accl, pf_dump, [] { __builtin_amdgcn_wave_barrier(); }, [] { __builtin_amdgcn_wave_barrier(); });
   } else {
     static_assert(KLDS == 0 || T <= 64, "key tiles through LDS: one wave per ciphertext");
-    pbs_thread<LOGN, K, L, P, MB, 0, 1, XG>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
+    pbs_thread<LOGN, K, L, P, MB>(A, t, tw, stage, exch, accl, pf_dump, [] { __syncthreads(); }, [] { __builtin_amdgcn_wave_barrier(); });
   }
 }
 

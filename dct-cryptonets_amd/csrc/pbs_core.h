@@ -215,9 +215,7 @@ struct pbs_args {
   int pf_rank, pf_parts;      // L2 warm-up: this workgroup touches part pf_rank of pf_parts of BSK[i + PF_DIST]
   const cplx* kring;          // KLDS: ring of key tiles in LDS shared by the KW waves of the workgroup (generic pointer for the reads)
   uint32_t kring_lds;         // ... its LDS byte address (what the LDS-DMA instruction takes in M0)
-  int kwave;                  // ... this wave's index among the KW (XG: this ciphertext's index among the XG of its workgroup)
-  const uint64_t* cts_all;    // XG: the launch's small ciphertexts, [count_all][n+1] ...
-  size_t e_first, count_all;  // ... the first ciphertext of this workgroup, the launch's count (ciphertexts past it repeat the last one)
+  int kwave;                  // ... this wave's index among the KW
 };
 
 // The whole bootstrap for one ciphertext, executed by thread t of its group.
@@ -237,7 +235,7 @@ struct pbs_args {
 // Protocol per step s: wait until this wave's DMAs of step s have landed (counted vmcnt: the younger ones stay in flight), workgroup
 // barrier (=> everybody's part of step s is there, and everybody is done reading step s - 1), issue the DMAs of step s + KLDS - 1 into
 // the tile step s - 1 used, read step s.
-template <int LOGN, int K, int L, int P, int MB = 0, int KLDS = 0, int KW = 1, int XG = 0, class Sync, class WSync>
+template <int LOGN, int K, int L, int P, int MB = 0, int KLDS = 0, int KW = 1, class Sync, class WSync>
 HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw, cplx* exch, uint64_t* accl_raw, uint32_t* pf_dump, Sync&& sync, WSync&& wsync) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
   constexpr int N = G::N, M = G::M, T = G::T, NL = G::NL;
@@ -356,119 +354,7 @@ HD void pbs_thread(const pbs_args& A, int t, const cplx* tw, uint64_t* stage_raw
     const uint32_t a = (uint32_t)(((A.ct_small[i] >> msh) + 1) >> 1) & (2 * N - 1);
     const cplx* bsk_i = make_uniform(A.bsk + (size_t)(A.bsk_wrap > 0 ? i % A.bsk_wrap : i) * G::BSK_ELEMS_PER_KEYBIT);
     cplx out[K + 1][P];
-    if constexpr (MB && !G::PAIR && XG > 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      // XG ciphertexts of a workgroup walk the key together, and a CU's vector L1 hands a wave 64 bytes per clock at best (DESIGN.md
-      // section 5: the products with the key ran AT that rate, every ciphertext pulling its own copy of the same lines).  So the spectra
-      // change hands instead: after each forward transform a thread parks its P points in its own wave's block of the exchange buffer;
-      // thread slot t of ciphertext g then takes points [g P/XG, (g+1) P/XG) of slot t of ALL XG ciphertexts, loads their key values
-      // once and multiplies them into XG ciphertexts (each with its own monomials); the sums go home the same way before the inverse
-      // transforms.  Key bytes through the L1 per ciphertext: 1/XG.  Same operations on the same values in the same order per
-      // (ciphertext, point) as the form below: bit-identical outputs.
-      static_assert(!KL && P % XG == 0 && T >= 64 && G::GROUP_BYTES % 16 == 0, "spectra change hands between whole waves");
-      constexpr int JPG = P / XG;                                       // points per thread slot and ciphertext this thread multiplies
-      constexpr int BLK = G::F::EXCH_ELEMS / (T / 64);                  // a wave's block of its ciphertext's exchange buffer (>= 64 P)
-      constexpr int GSTRIDE = G::GROUP_BYTES / 16;                      // from one ciphertext's exchange buffer to the next's
-      static_assert(BLK >= 64 * P, "a wave's block holds its P x 64 points");
-      const int gq = (int)DCTFHE_UNIFORM(A.kwave);
-      cplx* const blk = exch + (t >> 6) * BLK + (t & 63);
-      uint32_t ax[XG][2];                                                // both rotation amounts of the XG ciphertexts (wave-uniform)
-      static_for<0, XG>([&](auto Cc) {
-        constexpr int c = decltype(Cc)::value;
-        size_t ec = A.e_first + c;
-        if (ec >= A.count_all) ec = A.count_all - 1;
-        const uint64_t* cs = A.cts_all + ec * (size_t)(n + 1);
-        ax[c][0] = DCTFHE_UNIFORM((uint32_t)(((cs[i] >> msh) + 1) >> 1) & (2 * N - 1));
-        ax[c][1] = DCTFHE_UNIFORM((uint32_t)(((cs[i + 1] >> msh) + 1) >> 1) & (2 * N - 1));
-      });
-      const cplx* key = A.bsk + (size_t)(3 * (i >> 1)) * G::BSK_ELEMS_PER_KEYBIT;
-      cplx outT[XG][K + 1][JPG];
-      static_for<0, K + 1>([&](auto Pp) {
-        constexpr int p = decltype(Pp)::value;
-        static_assert(L <= 3, "packing holds two deferred digits");
-        uint32_t packed[2 * P];
-        double first[2 * P];
-        static_for<0, 2 * P>([&](auto R) {
-          constexpr int r = decltype(R)::value;
-          acc_t own;
-          if constexpr (p < NL) own = accl[p * N + t + T * r]; else own = acc[p][r];
-          int32_t dg[L];
-          decompose<L>(own, A.beta, dg);
-          first[r] = (double)dg[0];
-          uint32_t pk = 0;
-          if constexpr (L > 1) pk = (uint32_t)(uint16_t)(int16_t)dg[1];
-          if constexpr (L > 2) pk |= (uint32_t)(uint16_t)(int16_t)dg[2] << 16;
-          packed[r] = pk;
-        });
-        static_for<0, L>([&](auto Lv) {
-          constexpr int lev = decltype(Lv)::value;
-          constexpr int row = p * L + lev;
-          cplx v[P];
-          static_for<0, P>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            if constexpr (lev == 0) v[j] = cmk(first[j], first[P + j]);
-            else v[j] = cmk((double)(int16_t)(packed[j] >> (16 * (lev - 1))), (double)(int16_t)(packed[P + j] >> (16 * (lev - 1))));
-          });
-          // this row's key values: P/XG points x 3 blocks x (K+1) output polynomials per thread -- few enough to be asked for BEFORE the
-          // transform, so that they arrive under it
-          cplx kk[JPG][3][K + 1];
-          static_for<0, JPG>([&](auto Jj) {
-            constexpr int jj = decltype(Jj)::value;
-            const int jr = JPG * gq + jj;
-            static_for<0, 3>([&](auto Ww) {
-              constexpr int w = decltype(Ww)::value;
-              static_for<0, K + 1>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                kk[jj][w][q] = load_uniform_base(key + (((size_t)w * G::ROWS * (K + 1) + (size_t)row * (K + 1) + q) * M + (size_t)jr * T), (unsigned)t);
-              });
-            });
-          });
-          DCTFHE_SCHED_BARRIER();
-          fft_forward<G::LOGM, P>(v, t, tw, twist, exch, sync, wsync);
-          tick.template at<4>();
-          // park the spectrum (own wave's block: program order covers this wave's last gather; the other ciphertexts' reads of the
-          // previous row are behind the transform's workgroup barriers when it has any -- T > 64 -- and behind this one otherwise)
-          if constexpr (T <= 64) __syncthreads();
-          static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; blk[j * 64] = v[j]; });
-          __syncthreads();
-          static_for<0, JPG>([&](auto Jj) {
-            constexpr int jj = decltype(Jj)::value;
-            const int jr = JPG * gq + jj;                               // the point (of every thread slot) handled here: wave-uniform
-            const uint32_t gsm = (uint32_t)jr / G::RL, jp = (uint32_t)jr % G::RL;
-            static_for<0, XG>([&](auto Cc) {
-              constexpr int c = decltype(Cc)::value;
-              const cplx vt = (blk + (c - gq) * GSTRIDE)[jr * 64];
-              cplx z1 = zeta((ax[c][0] * ulow0 - ax[c][0] * (USTEP * gsm)) & (2 * N - 1));
-              cplx z2 = zeta((ax[c][1] * ulow0 - ax[c][1] * (USTEP * gsm)) & (2 * N - 1));
-              if constexpr (G::RL > 1) {                                 // (jp = 0: times exactly 1)
-                z1 = cmul(z1, root8((0u - ax[c][0] * jp) * (8 / G::RL)));
-                z2 = cmul(z2, root8((0u - ax[c][1] * jp) * (8 / G::RL)));
-              }
-              const cplx m1 = cmk(z1.re - 1.0, z1.im), m2 = cmk(z2.re - 1.0, z2.im);
-              cplx m12 = cmul(z1, z2); m12.re -= 1.0;
-              static_for<0, K + 1>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                const cplx bundle = cfma(m12, kk[jj][2][q], cfma(m2, kk[jj][1][q], cmul(m1, kk[jj][0][q])));
-                if constexpr (row == 0) outT[c][q][jj] = cmul(vt, bundle); else outT[c][q][jj] = cfma(vt, bundle, outT[c][q][jj]);
-              });
-            });
-          });
-          tick.template at<5>();
-        });
-      });
-      // the sums go home, one output polynomial at a time through the same blocks
-      static_for<0, K + 1>([&](auto Q) {
-        constexpr int q = decltype(Q)::value;
-        __syncthreads();                                                 // everybody has read what these blocks held
-        static_for<0, XG>([&](auto Cc) {
-          constexpr int c = decltype(Cc)::value;
-          static_for<0, JPG>([&](auto Jj) { constexpr int jj = decltype(Jj)::value; (blk + (c - gq) * GSTRIDE)[(JPG * gq + jj) * 64] = outT[c][q][jj]; });
-        });
-        __syncthreads();
-        static_for<0, P>([&](auto J) { constexpr int j = decltype(J)::value; out[q][j] = blk[j * 64]; });
-      });
-#endif
-    } else if constexpr (MB && !G::PAIR) {
+    if constexpr (MB && !G::PAIR) {
       // general (k, l): one polynomial at a time through the single exchange buffer; the monomial factors are rebuilt per
       // gadget row (holding them for all P points would take 96 registers).  ACC polynomials that live in LDS are only
       // ever touched by their owner here -- there is no rotation -- so no barrier guards them.

@@ -7,11 +7,11 @@
 using namespace dctfhe;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int LOGN, int K, int L, int P, int GR, int MB = 0, int KLDS = 0, int XG = 0>
+template <int LOGN, int K, int L, int P, int GR, int MB = 0, int KLDS = 0>
 void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   using G = pbs_geom<LOGN, K, L, P, MB>;
   // every case announces itself BEFORE it launches: a fault then names its case (profiles/r01_exp_two_bit_rotation.log did not)
-  printf("case xg=%d mb=%d klds=%d pf=%d wrap=%d N=%d k=%d l=%d P=%d groups=%d n=%d count=%zu ...\n", XG, MB, KLDS, pf, wrap, 1 << LOGN, K, L, P, GR, n, count);
+  printf("case mb=%d klds=%d pf=%d wrap=%d N=%d k=%d l=%d P=%d groups=%d n=%d count=%zu ...\n", MB, KLDS, pf, wrap, 1 << LOGN, K, L, P, GR, n, count);
   fflush(stdout);
   if (pf != 0 && pf < 8) { printf("pf_parts must be 0 or >= 8 (kernel contract, pbs_core.h)\n"); return; }
   if (MB && wrap) { printf("wrap is not supported by the two-bit kernels\n"); return; }
@@ -37,18 +37,18 @@ void run(int n, int beta, size_t count, int D, int wrap = 0, int pf = 0) {
   pbs_launch a; a.cts_small = d_small; a.count = count; a.n = n; a.beta = beta; a.bsk = d_bsk; a.tw = d_tw; a.wtab = d_wtab; a.tables = d_tab; a.w = 4; a.table_idx = nullptr;
   a.hw = 1; a.nchan = 1; a.e_offset = 0; a.out = d_out; a.D_out = D; a.accumulate = 0; a.body_add = 0; a.dummy = d_dummy; a.bsk_wrap = wrap; a.pf_parts = pf;
   const size_t lds = pbs_lds_bytes<LOGN, K, L, P, MB, KLDS>(GR);
-  CK(hipFuncSetAttribute((const void*)pbs_kernel<LOGN, K, L, P, GR, MB, KLDS, XG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)pbs_kernel<LOGN, K, L, P, GR, MB, KLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((count + GR - 1) / GR);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((pbs_kernel<LOGN, K, L, P, GR, MB, KLDS, XG>), dim3(grid), dim3(G::T * GR), lds, 0, a);
+  hipLaunchKernelGGL((pbs_kernel<LOGN, K, L, P, GR, MB, KLDS>), dim3(grid), dim3(G::T * GR), lds, 0, a);
   CK(hipDeviceSynchronize());
   hipEventRecord(e0);
-  hipLaunchKernelGGL((pbs_kernel<LOGN, K, L, P, GR, MB, KLDS, XG>), dim3(grid), dim3(G::T * GR), lds, 0, a);
+  hipLaunchKernelGGL((pbs_kernel<LOGN, K, L, P, GR, MB, KLDS>), dim3(grid), dim3(G::T * GR), lds, 0, a);
   hipEventRecord(e1); CK(hipEventSynchronize(e1));
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double fft = 5.0 * M * log2((double)M);
   const double fl = n * ((K + 1) * L * fft + (K + 1) * fft + (double)(K + 1) * (K + 1) * L * M * 8.0);
-  printf("xg=%d mb=%d klds=%d pf=%d wrap=%d N=%5d k=%d l=%d P=%2d groups=%d threads=%4d lds=%6zu: %zu cts %.1f ms -> %.0f PBS/s, %.2f TFLOP/s\n", XG, MB, KLDS, pf, wrap, N, K, L, P, GR, G::T * GR, lds, count, ms,
+  printf("mb=%d klds=%d pf=%d wrap=%d N=%5d k=%d l=%d P=%2d groups=%d threads=%4d lds=%6zu: %zu cts %.1f ms -> %.0f PBS/s, %.2f TFLOP/s\n", MB, KLDS, pf, wrap, N, K, L, P, GR, G::T * GR, lds, count, ms,
          count / (ms * 1e-3), fl * count / (ms * 1e-3) / 1e12);
   fflush(stdout);
 #if defined(DCTFHE_PHASE_TIMERS)
