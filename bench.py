@@ -510,6 +510,8 @@ def main():
             instr = vi[0] * vi[1] * (td.n / unroll) * cts_per_launch
             res["roofline_valu_issue"] = {"bound": "valu_issue", "achieved": instr / avg_launch_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
                                           "frac": instr / avg_launch_s / VALU_ISSUE_PEAK, "valu_instr_per_iteration_per_wave": vi[0], "waves_per_ciphertext": vi[1],
+                                          # what the power limit lets a pure f64 FMA stream issue on this box, in wave instructions per second
+                                          "peak_live_fma_probe": fp64_live * 1e12 / 2 / 64 / 1e9, "frac_of_live_probe": instr / avg_launch_s / (fp64_live * 1e12 / 2 / 64),
                                           "note": "instruction counts from the ISA of the shipped build; peak at the 2.4 GHz spec clock (the kernels hold 2.04-2.38 GHz)"}
         # The other roof, found with the phase clock of tools/exp_pbs.hip (profiles/r03_exp_phase_clock.log): every ciphertext pulls the whole
         # Fourier key through its CU's vector L1 once -- bsk_bytes per ciphertext, never reused inside the CU -- and a CU's L1 hands at most
