@@ -40,8 +40,8 @@ FP64_SPEC_TFLOPS = 78.6          # MI355X vector FP64 (spec; the guide does not 
 
 # VALU instructions per blind-rotate loop iteration and wave, and waves per ciphertext, of the bootstrap kernels (ISA listing of the
 # shipped build: hipcc -S + tools/isa_hist.py).  key: (logN, k, l, unroll).  An iteration consumes `unroll` key bits.
-VALU_PER_ITERATION = {(13, 1, 1, 2): (2433, 8), (12, 1, 1, 2): (2365, 4), (11, 1, 1, 2): (2325, 2), (11, 1, 3, 1): (4511, 2), (11, 1, 3, 2): (6171, 2), (10, 2, 1, 1): (2792, 1),
-                      (10, 2, 1, 2): (3802, 1), (10, 2, 2, 1): (4745, 1)}
+VALU_PER_ITERATION = {(13, 1, 1, 2): (2275, 8), (12, 1, 1, 2): (2203, 4), (11, 1, 1, 2): (2156, 2), (11, 1, 3, 1): (4329, 2), (11, 1, 3, 2): (5968, 2), (10, 2, 1, 1): (2579, 1),
+                      (10, 2, 1, 2): (3589, 1), (10, 2, 2, 1): (4520, 1)}      # final round-3 build (tools/isa_hist.py: f64 + other VALU of the loop body)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4          # wave-instructions per second: 256 CUs x 4 SIMDs, one f64 wave instruction per 4 cycles, 2.4 GHz
 N_CU, SPEC_CLOCK_HZ = 256, 2.4e9
 L1_DELIVERY_BYTES_PER_CLK_CU = 64.0            # a CU's vector L1 returns one 64-byte half line per clock to the registers (a wave's 16 B/lane load: 16 clocks);

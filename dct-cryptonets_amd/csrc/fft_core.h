@@ -39,6 +39,10 @@
 #ifndef DCTFHE_PIPE_LOCAL
 #define DCTFHE_PIPE_LOCAL 0
 #endif
+// Middle passes of the inverse transforms as fused butterflies (fused_idft below): 1 = on
+#ifndef DCTFHE_FUSED_INV
+#define DCTFHE_FUSED_INV 1
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DCTFHE_PIPE_PIN)
 #define DCTFHE_PIPE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -156,6 +160,49 @@ struct small_dft {
     }
   }
 };
+
+// Size-R DFT (e^{+2 pi i m k / R}) of z[m] = x[m S] c^m -- the twiddled passes of the inverse transform -- with the twiddles INSIDE the
+// butterflies: decimation in time, z[2m'] = x[2m' S] (c^2)^m' and z[2m'+1] = c x[(2m'+1) S] (c^2)^m', so
+//   Y[k], Y[k + R/2] = E[k] +- (c omega_R^k) O'[k]        (E, O': the two half-size transforms with base c^2)
+// and a butterfly a +- t b is p = fma(t, b, a) (two fma per component) and m = 2a - p (one): 6 f64 instructions where the multiplication
+// and the two additions took 8, and the 7-step power chain c^1 .. c^7 is replaced by c^2, c^4 (squarings) and c omega_8 -- the other
+// factors are those times i, a matter of which operand goes where.  pw[l] = c^(2^l); cw8 = c e^{+2 pi i / 8}.
+HD void fused_bf(const cplx a, const cplx b, const double tr, const double ti, cplx& p, cplx& m) {
+  p.re = __builtin_fma(tr, b.re, __builtin_fma(-ti, b.im, a.re));
+  p.im = __builtin_fma(tr, b.im, __builtin_fma(ti, b.re, a.im));
+  m.re = __builtin_fma(2.0, a.re, -p.re);
+  m.im = __builtin_fma(2.0, a.im, -p.im);
+}
+template <int R, int S, int LV>
+struct fused_idft {
+  static HD void run(const cplx* x, cplx* y, const cplx* pw, const cplx cw8) {
+    static_assert(R == 2 || R == 4 || R == 8, "radix 8 passes");
+    if constexpr (R == 2) {
+      fused_bf(x[0], x[S], pw[LV].re, pw[LV].im, y[0], y[1]);
+    } else {
+      cplx e[R / 2], o[R / 2];
+      fused_idft<R / 2, 2 * S, LV + 1>::run(x, e, pw, cw8);
+      fused_idft<R / 2, 2 * S, LV + 1>::run(x + S, o, pw, cw8);
+      const cplx c = pw[LV];
+      fused_bf(e[0], o[0], c.re, c.im, y[0], y[R / 2]);
+      if constexpr (R == 4) {
+        fused_bf(e[1], o[1], -c.im, c.re, y[1], y[1 + R / 2]);                 // t = i c
+      } else {
+        fused_bf(e[1], o[1], cw8.re, cw8.im, y[1], y[1 + R / 2]);              // t = c omega_8
+        fused_bf(e[2], o[2], -c.im, c.re, y[2], y[2 + R / 2]);                 // t = i c
+        fused_bf(e[3], o[3], -cw8.im, cw8.re, y[3], y[3 + R / 2]);             // t = i c omega_8
+      }
+    }
+  }
+};
+// the prepared factors of a pass from its twiddle base b (c = conj b)
+HD void fused_idft_factors(const cplx b, cplx* pw, cplx& cw8) {
+  constexpr double h = 0.70710678118654752440;
+  pw[0] = cmk(b.re, -b.im);
+  pw[1] = csqr(pw[0]);
+  pw[2] = csqr(pw[1]);
+  cw8 = cmk(h * (pw[0].re - pw[0].im), h * (pw[0].re + pw[0].im));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Geometry of the in-place mixed-radix transform for (log2 M, P)
@@ -294,7 +341,8 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch
     constexpr int i = S - 1 - decltype(Irev)::value;
     constexpr int R = G::radix(i);
     constexpr int W = G::weight(i);
-    if constexpr (i < S - 1) {
+    constexpr bool FUSED = DCTFHE_FUSED_INV && i > 0 && i < S - 1 && R == P && P == 8;
+    if constexpr (i < S - 1 && !FUSED) {
       const cplx b = tw[G::tw_offset(i) + (t % W)];
       {
         cplx run = (i == 0) ? twist : cmk(1.0, 0.0);
@@ -303,7 +351,11 @@ HD void fft_inverse(cplx* v, int t, const cplx* tw, const cplx twist, cplx* exch
       }
     }
     cplx y[P];
-    if constexpr (R == P) {
+    if constexpr (FUSED) {
+      cplx pw[3], cw8;
+      fused_idft_factors(tw[G::tw_offset(i) + (t % W)], pw, cw8);
+      fused_idft<P, 1, 0>::run(v, y, pw, cw8);
+    } else if constexpr (R == P) {
       small_dft<P, 1, +1>::run(v, y);
     } else {
       static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v + g * R, y + g * R); });
@@ -491,8 +543,11 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
       });
       return;
     }
+    constexpr bool FUSED = DCTFHE_FUSED_INV && i > 0 && i < S - 1 && R == P && P == 8;
+    [[maybe_unused]] cplx pw[3], cw8;
+    if constexpr (FUSED) fused_idft_factors(b, pw, cw8);
 #if DCTFHE_SHARED_TWIDDLES
-    if constexpr (i < S - 1) {
+    if constexpr (i < S - 1 && !FUSED) {
       cplx run = run0;
       if constexpr (i == 0) static_for<0, NP>([&](auto U) { constexpr int u = decltype(U)::value; v[u][0] = cmulc(v[u][0], run); });
       static_for<1, R>([&](auto K) {
@@ -505,14 +560,16 @@ HD void fft_inverse_n(cplx (&v)[NP][P], int t, const cplx* tw, const cplx twist,
     static_for<0, NP>([&](auto U) {
       constexpr int u = decltype(U)::value;
 #if !DCTFHE_SHARED_TWIDDLES
-      if constexpr (i < S - 1) {
+      if constexpr (i < S - 1 && !FUSED) {
         cplx run = run0;
         if constexpr (i == 0) v[u][0] = cmulc(v[u][0], run);
         static_for<1, R>([&](auto K) { constexpr int k = decltype(K)::value; run = cmul(run, b); v[u][k] = cmulc(v[u][k], run); });
       }
 #endif
       cplx y[P];
-      if constexpr (R == P) {
+      if constexpr (FUSED) {
+        fused_idft<P, 1, 0>::run(v[u], y, pw, cw8);
+      } else if constexpr (R == P) {
         small_dft<P, 1, +1>::run(v[u], y);
       } else {
         static_for<0, P / R>([&](auto Gp) { constexpr int g = decltype(Gp)::value; small_dft<R, 1, +1>::run(v[u] + g * R, y + g * R); });
